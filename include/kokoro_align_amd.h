@@ -1,0 +1,124 @@
+/*
+ * kokoro_align_amd.h — C ABI of the MI355X (gfx950) CTC forced-alignment hot path.
+ *
+ * Drop-in boundary for the alignment step of kaiidams/Kokoro-Align.  The reference has no
+ * FFI layer: its boundary is three Python functions in kokoro_align/align.py.  Each entry
+ * point below names the reference interface it replaces (file:line); the Python mirror
+ * that keeps the reference's signatures lives in kokoro-align_amd/align.py and binds these
+ * symbols with ctypes.
+ *
+ * Plain pointers and sizes only; no torch types.  Device pointers may come from any
+ * allocator (hipMalloc, a torch tensor's data_ptr(), ...).  The library never retains a
+ * caller pointer after a call returns.
+ *
+ * Thread-safety: one ka_engine per host thread / stream; distinct engines are independent.
+ */
+#ifndef KOKORO_ALIGN_AMD_H
+#define KOKORO_ALIGN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KA_VERSION 100 /* 0.1.0 */
+
+/* status codes (per call and per lattice) */
+#define KA_OK 0
+#define KA_ERR_EMPTY_BEAM (-1) /* no live state in the last frame: reference raises ValueError, align.py:101 */
+#define KA_ERR_BAD_ARGS (-2)
+#define KA_ERR_HIP (-3)       /* HIP runtime error, text in ka_last_error() */
+#define KA_ERR_NOMEM (-4)
+#define KA_ERR_BAD_LABEL (-5) /* label outside [0,V): reference raises IndexError at align.py:77 */
+
+/* where the caller's buffers live */
+#define KA_MEM_HOST 0
+#define KA_MEM_DEVICE 1
+
+typedef struct ka_engine ka_engine;
+
+int32_t ka_version(void);
+/* message of the last error on the calling thread ("" if none) */
+const char *ka_last_error(void);
+
+/* An engine owns the device workspace (back-pointer storage, padded labels, descriptors),
+ * pinned staging and timing events for ONE device.  device = HIP ordinal. */
+int ka_engine_create(int32_t device, ka_engine **out);
+void ka_engine_destroy(ka_engine *e);
+/* pre-size the workspace so that later calls do not allocate (optional) */
+int ka_engine_reserve(ka_engine *e, size_t workspace_bytes);
+/* device-workspace bytes one batch call needs (back-pointers dominate: 256 B per frame) */
+size_t ka_workspace_bytes(int32_t n, const int64_t *T, const int64_t *S, int32_t V,
+                          int32_t beam_size, int32_t max_move);
+
+/*
+ * ctc_best_path(log_probs, labels, beam_size=1000, max_move=4) -> (best_path, best_labels, best_scores)
+ * replaces kokoro_align/align.py:43-109 (DP align.py:62-93, backtrace :21-40,:99-102, gathers :105-107).
+ *
+ *   log_probs  [T, V] float32, row stride ld (elements)
+ *   labels     [S] int32, values in [0, V)   (un-expanded transcript; blanks are inserted here)
+ *   best_path  [T] int32  positions in the blank-expanded label sequence (0 .. 2S)
+ *   best_labels[T] int32, best_scores [T] float32 (per-frame emission of the chosen label)
+ *   total_score  optional (may be NULL): cumulative float32 score of the terminal state
+ *   mem        KA_MEM_HOST: all pointers are host memory (the call copies in and out)
+ *              KA_MEM_DEVICE: all pointers except total_score are device memory
+ *   stream     hipStream_t to launch on (NULL = default stream).  The call returns after the
+ *              outputs are valid (it synchronises the stream).
+ * Returns KA_OK, KA_ERR_EMPTY_BEAM (-> ValueError), KA_ERR_BAD_LABEL, KA_ERR_BAD_ARGS, KA_ERR_HIP.
+ */
+int ka_ctc_best_path_f32(ka_engine *e, const float *log_probs, int64_t T, int32_t V, int64_t ld,
+                         const int32_t *labels, int64_t S, int32_t beam_size, int32_t max_move,
+                         int32_t *best_path, int32_t *best_labels, float *best_scores,
+                         float *total_score, int32_t mem, void *stream);
+
+/*
+ * The same over n independent lattices (one per audio file; the reference loops files
+ * sequentially, run_example.py:248-254).  Arrays of n pointers / sizes are HOST arrays;
+ * the pointed-to buffers live where `mem` says.  status[n] and total_score[n] are host
+ * arrays (either may be NULL).  Returns KA_OK if every lattice succeeded, otherwise the
+ * status of the first lattice that failed; the other lattices' outputs are still valid.
+ */
+int ka_ctc_best_path_batch_f32(ka_engine *e, int32_t n, const float *const *log_probs,
+                               const int64_t *T, int32_t V, const int64_t *ld,
+                               const int32_t *const *labels, const int64_t *S,
+                               int32_t beam_size, int32_t max_move, int32_t *const *best_path,
+                               int32_t *const *best_labels, float *const *best_scores,
+                               float *total_score, int32_t *status, int32_t mem, void *stream);
+
+/* Split form for device-resident batches: enqueue launches everything on `stream` without a
+ * host sync; finish synchronises and fetches per-lattice status / total scores. */
+int ka_ctc_best_path_batch_enqueue_f32(ka_engine *e, int32_t n, const float *const *log_probs,
+                                       const int64_t *T, int32_t V, const int64_t *ld,
+                                       const int32_t *const *labels, const int64_t *S,
+                                       int32_t beam_size, int32_t max_move,
+                                       int32_t *const *best_path, int32_t *const *best_labels,
+                                       float *const *best_scores, void *stream);
+int ka_batch_finish(ka_engine *e, float *total_score, int32_t *status);
+
+/* Per-kernel timing of the LAST enqueued batch, measured with HIP events recorded on the
+ * launch stream: ms[0] label prep, ms[1] forward DP, ms[2] backtrace + gathers.
+ * Enable before the call; costs two events per kernel. */
+int ka_engine_set_profiling(ka_engine *e, int32_t on);
+int ka_engine_last_kernel_ms(ka_engine *e, float ms[3]);
+
+/*
+ * Mean-subtracted log-softmax of kokoro_align/align.py:116-117 on device:
+ *   x = logits - mean(logits, -1);  log_probs = x - log(sum(exp(x), -1))
+ * (float32, not max-subtracted, like the reference).  In-place allowed.
+ */
+int ka_log_softmax_f32(const float *logits, float *log_probs, int64_t T, int32_t V,
+                       int64_t ld_in, int64_t ld_out, void *stream);
+
+/* Bit-reproducible synthetic inputs generated in HBM (same definition as the CPU oracle's
+ * hash generator):  lp[t,c] = -8*u24(mix(seed, t*V+c)),
+ * labels[k] = 1 + mix(seed^salt, k) % (V-1). */
+int ka_hash_logprobs_f32(float *dev_log_probs, int64_t T, int32_t V, int64_t ld, uint64_t seed,
+                         void *stream);
+int ka_hash_labels_i32(int32_t *dev_labels, int64_t S, int32_t V, uint64_t seed, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KOKORO_ALIGN_AMD_H */

@@ -1,0 +1,159 @@
+"""ctypes binding of include/kokoro_align_amd.h (the C-ABI drop-in boundary).
+
+The shared library is built in-tree by ``build_library()`` (kokoro-align_amd/csrc/Makefile,
+hipcc --offload-arch=gfx950) and loaded from the package directory.  A missing library is an
+error: there is no fallback implementation.
+"""
+import ctypes
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_PKG, "libkokoro_align_amd.so")
+_lib = None
+
+KA_OK = 0
+KA_ERR_EMPTY_BEAM = -1
+KA_ERR_BAD_ARGS = -2
+KA_ERR_HIP = -3
+KA_ERR_NOMEM = -4
+KA_ERR_BAD_LABEL = -5
+KA_MEM_HOST = 0
+KA_MEM_DEVICE = 1
+
+EXPORTS = [
+    "ka_version", "ka_last_error", "ka_engine_create", "ka_engine_destroy", "ka_engine_reserve",
+    "ka_workspace_bytes", "ka_ctc_best_path_f32", "ka_ctc_best_path_batch_f32",
+    "ka_ctc_best_path_batch_enqueue_f32", "ka_batch_finish", "ka_engine_set_profiling",
+    "ka_engine_last_kernel_ms", "ka_log_softmax_f32", "ka_hash_logprobs_f32", "ka_hash_labels_i32",
+]
+
+
+class KAError(RuntimeError):
+    """A C-ABI call failed (HIP error, bad arguments, out of memory)."""
+
+
+def library_path():
+    return _SO
+
+
+def build_library(force=False):
+    """Compile the HIP library for gfx950 (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_PKG, "csrc", f) for f in ("ka_engine.hip", "ka_kernels.hpp")]
+    srcs.append(os.path.join(os.path.dirname(_PKG), "include", "kokoro_align_amd.h"))
+    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_PKG, "csrc")] + (["-B"] if force else []))
+    return _SO
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise KAError(
+            f"{_SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C kokoro-align_amd/csrc` (there is no CPU fallback)")
+    L = ctypes.CDLL(_SO)
+    i32, i64, u64, vp, sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_size_t
+    pp = ctypes.POINTER(vp)
+    pi64 = ctypes.POINTER(i64)
+    L.ka_version.restype = i32
+    L.ka_version.argtypes = []
+    L.ka_last_error.restype = ctypes.c_char_p
+    L.ka_last_error.argtypes = []
+    L.ka_engine_create.restype = ctypes.c_int
+    L.ka_engine_create.argtypes = [i32, pp]
+    L.ka_engine_destroy.restype = None
+    L.ka_engine_destroy.argtypes = [vp]
+    L.ka_engine_reserve.restype = ctypes.c_int
+    L.ka_engine_reserve.argtypes = [vp, sz]
+    L.ka_workspace_bytes.restype = sz
+    L.ka_workspace_bytes.argtypes = [i32, pi64, pi64, i32, i32, i32]
+    L.ka_ctc_best_path_f32.restype = ctypes.c_int
+    L.ka_ctc_best_path_f32.argtypes = [vp, vp, i64, i32, i64, vp, i64, i32, i32, vp, vp, vp, vp, i32, vp]
+    batch_common = [vp, i32, pp, pi64, i32, pi64, pp, pi64, i32, i32, pp, pp, pp]
+    L.ka_ctc_best_path_batch_f32.restype = ctypes.c_int
+    L.ka_ctc_best_path_batch_f32.argtypes = batch_common + [vp, vp, i32, vp]
+    L.ka_ctc_best_path_batch_enqueue_f32.restype = ctypes.c_int
+    L.ka_ctc_best_path_batch_enqueue_f32.argtypes = batch_common + [vp]
+    L.ka_batch_finish.restype = ctypes.c_int
+    L.ka_batch_finish.argtypes = [vp, vp, vp]
+    L.ka_engine_set_profiling.restype = ctypes.c_int
+    L.ka_engine_set_profiling.argtypes = [vp, i32]
+    L.ka_engine_last_kernel_ms.restype = ctypes.c_int
+    L.ka_engine_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    L.ka_log_softmax_f32.restype = ctypes.c_int
+    L.ka_log_softmax_f32.argtypes = [vp, vp, i64, i32, i64, i64, vp]
+    L.ka_hash_logprobs_f32.restype = ctypes.c_int
+    L.ka_hash_logprobs_f32.argtypes = [vp, i64, i32, i64, u64, vp]
+    L.ka_hash_labels_i32.restype = ctypes.c_int
+    L.ka_hash_labels_i32.argtypes = [vp, i64, i32, u64, vp]
+    _lib = L
+    return L
+
+
+def last_error():
+    return load_library().ka_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what):
+    """Map a C status to the exception the reference would raise."""
+    if rc == KA_OK:
+        return
+    msg = last_error()
+    if rc == KA_ERR_EMPTY_BEAM:
+        # reference: np.argmax of an empty array at kokoro_align/align.py:101
+        raise ValueError("attempt to get argmax of an empty sequence")
+    if rc == KA_ERR_BAD_LABEL:
+        # reference: log_probs[i, labels[v]] at kokoro_align/align.py:77
+        raise IndexError(f"{what}: label out of bounds for the vocabulary axis ({msg})")
+    if rc == KA_ERR_BAD_ARGS:
+        raise ValueError(f"{what}: {msg}")
+    if rc == KA_ERR_NOMEM:
+        raise MemoryError(f"{what}: {msg}")
+    raise KAError(f"{what}: rc={rc}: {msg}")
+
+
+class Engine:
+    """Owns a ka_engine (device workspace + staging) for one device."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        check(self.lib.ka_engine_create(int(device), ctypes.byref(h)), "ka_engine_create")
+        self.handle = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.ka_engine_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_profiling(self, on=True):
+        check(self.lib.ka_engine_set_profiling(self.handle, int(bool(on))), "ka_engine_set_profiling")
+
+    def last_kernel_ms(self):
+        ms = (ctypes.c_float * 3)()
+        check(self.lib.ka_engine_last_kernel_ms(self.handle, ms), "ka_engine_last_kernel_ms")
+        return {"prep": ms[0], "forward": ms[1], "backtrace": ms[2]}
+
+    def reserve(self, nbytes):
+        check(self.lib.ka_engine_reserve(self.handle, int(nbytes)), "ka_engine_reserve")
+
+
+_engines = {}
+
+
+def default_engine(device=0):
+    e = _engines.get(device)
+    if e is None:
+        e = _engines[device] = Engine(device)
+    return e

@@ -1,0 +1,664 @@
+// ka_kernels.hpp — gfx950 (CDNA4) device code of the CTC best-path hot path.
+//
+// What is computed (dense-band form of kokoro_align/align.py:43-109):
+//   lab'[p] = p odd ? labels[p/2] : 0;  A_{-1} = {0}, sc_{-1}[0] = 0
+//   frame t:  lo = max(0, floor(L*t/T) - B/2), hi = min(lo+B, L)            (align.py:64-65)
+//     p in [lo,hi):  c_j = sc_{t-1}[p-j] (+) lp[t, lab'[p]]  (float32 add, then compare)
+//                    j even, j>0, lab'[p]==0  ->  c_j = -inf                (align.py:80-81)
+//                    j* = first j attaining the max; bp_t[p] = j*           (align.py:83-85)
+//   end = highest live position of frame T-1; walk bp back to frame 0       (align.py:99-102)
+//
+// Layout of the fast path ("w16": one 64-lane wavefront owns one lattice):
+//   * 1024 slots = 64 lanes x 16 cells; position p lives in slot p mod 1024,
+//     lane (p>>4)&63, cell p&15.  The live band is at most 1009 wide, so the 64 blocks
+//     [lo>>4, (lo>>4)+63] never alias; as `lo` passes a block its lane is re-labelled
+//     for block+64.  No data ever moves when the band slides.
+//   * scores live in 16 VGPRs per lane; the three neighbours p-1..p-3 of a lane's first
+//     cells come from the previous lane with DPP wave_ror:1 (fused into v_add_f32_dpp).
+//   * lane v of a "row" register holds lp[t, v] (V <= 64): one coalesced 256-B load per
+//     frame, prefetched 4 frames ahead; blank emission = readfirstlane, label emissions
+//     = 8 ds_bpermute per frame (no LDS memory, no bank conflicts), issued one frame ahead.
+//   * max-of-(3|4) as a tournament of v_cmp_gt_f32 -> SGPR lane masks; the 2 back-pointer
+//     bits are combined on the scalar unit and shifted into a per-lane 32-bit word with
+//     v_addc_co_u32 (word = 2*word + bit): 16 cells x 2 bit = one dword per lane per
+//     frame = one coalesced 256-B store per frame.
+//   * the band [lo,hi) is applied with 16 wave-uniform 64-bit lane masks (one per cell
+//     index) held in SGPRs and updated only when lo/hi move.
+// No MFMA: ~7 flop per cell, nothing to contract.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ka {
+
+constexpr int kStatusOk = 0;
+constexpr int kStatusEmptyBeam = -1;
+constexpr int kStatusBadLabel = -5;
+
+constexpr int kSlots = 1024;        // 64 lanes x 16 cells
+constexpr int kFastMaxBand = 1009;  // kSlots - 15: widest band the w16 layout can hold
+constexpr int kRowDepth = 4;        // log-prob rows in flight per wave
+
+struct Lattice {
+    const float *lp;        // [T, ld] log-probs (device)
+    const int32_t *labels;  // [S] caller labels (device)
+    int32_t *labx;          // [labx_len] 4*label of odd position 2i+1, zero padded (workspace)
+    void *bp;               // w16: uint32 [T][64]; generic: uint8 [T][W]
+    float *col;             // generic only: 2 x L float scores followed by 2 x L present bytes
+    int32_t *path;          // [T] outputs (device)
+    int32_t *lab_out;
+    float *sc_out;
+    int64_t ld;
+    int32_t T, S, L, V;
+    int32_t beam, max_move;
+    int32_t labx_len, W;    // W = min(beam, L)
+    int32_t idx, pad;       // index of this lattice in the caller's batch
+};
+
+// meta[4*idx + {0,1,2,3}] = status, end position, flags (bit0: a transcript label is 0), total score bits
+__device__ __forceinline__ int32_t *meta_of(int32_t *meta, int idx) { return meta + 4 * (size_t)idx; }
+
+// ---------------------------------------------------------------------------------------
+// label preparation: validate, scale by 4 (ds_bpermute byte address), zero-pad
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prep_labels_kernel(const Lattice *__restrict__ lats, int32_t *meta)
+{
+    const Lattice &d = lats[blockIdx.x];
+    int bad = 0, zero = 0;
+    for (int i = threadIdx.x; i < d.labx_len; i += blockDim.x) {
+        int v = 0;
+        if (i < d.S) {
+            int l = d.labels[i];
+            if (l < 0 || l >= d.V) { bad = 1; l = 0; }
+            if (l == 0) zero = 1;
+            v = l * 4;
+        }
+        d.labx[i] = v;
+    }
+    int32_t *m = meta_of(meta, d.idx);
+    if (bad) atomicMin(&m[0], kStatusBadLabel);
+    if (zero) atomicOr(&m[2], 1);
+}
+
+// ---------------------------------------------------------------------------------------
+// small helpers (wave64)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float ninf() { return -__builtin_inff(); }
+
+// lane i <- lane i-1, lane 0 <- lane 63 (DPP wave_ror:1)
+__device__ __forceinline__ float wave_ror1(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x13C, 0xF, 0xF, false));
+}
+// 64-bit lane mask of (a > b), ordered compare
+__device__ __forceinline__ uint64_t fgt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 2 /*FCMP_OGT*/); }
+// w = 2*w + mask[lane]
+__device__ __forceinline__ uint32_t shl1_in(uint32_t w, uint64_t mask)
+{
+    uint32_t r;
+    uint64_t carry_out;
+    asm("v_addc_co_u32 %0, %1, %2, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(w), "s"(mask));
+    return r;
+}
+// mask[lane] ? b : a
+__device__ __forceinline__ float select_by_mask(float a, float b, uint64_t mask)
+{
+    float r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+    return r;
+}
+__device__ __forceinline__ float bperm(int byte_addr, float src)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, src)));
+}
+__device__ __forceinline__ float first_lane(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+
+// Lane masks of the band: m<k> has bit ((p>>4)&63) set for every p in [lo,hi) with p&15 == k.
+// A struct of named members (not an array): members can only be addressed with constant
+// indices, so the masks stay in SGPR pairs (an array indexed through the switch below is
+// turned into a dynamically indexed vector and lands in VGPRs).
+struct BandMasks {
+    uint64_t m0, m1, m2, m3, m4, m5, m6, m7, m8, m9, m10, m11, m12, m13, m14, m15;
+    template <int K>
+    __device__ __forceinline__ uint64_t &at()
+    {
+        if constexpr (K == 0) return m0;
+        else if constexpr (K == 1) return m1;
+        else if constexpr (K == 2) return m2;
+        else if constexpr (K == 3) return m3;
+        else if constexpr (K == 4) return m4;
+        else if constexpr (K == 5) return m5;
+        else if constexpr (K == 6) return m6;
+        else if constexpr (K == 7) return m7;
+        else if constexpr (K == 8) return m8;
+        else if constexpr (K == 9) return m9;
+        else if constexpr (K == 10) return m10;
+        else if constexpr (K == 11) return m11;
+        else if constexpr (K == 12) return m12;
+        else if constexpr (K == 13) return m13;
+        else if constexpr (K == 14) return m14;
+        else return m15;
+    }
+};
+template <int K>
+__device__ __forceinline__ void band_rebuild_one(BandMasks &mk, uint32_t lo, uint32_t hi)
+{
+    const uint32_t first = (lo + 15u - (uint32_t)K) >> 4;  // ceil((lo-K)/16)
+    const uint32_t last = (hi + 15u - (uint32_t)K) >> 4;
+    const uint32_t cnt = last - first;
+    const uint64_t m = cnt >= 64u ? ~0ull : ((1ull << cnt) - 1ull);
+    const uint32_t r = first & 63u;
+    mk.at<K>() = r ? ((m << r) | (m >> (64u - r))) : m;
+    if constexpr (K < 15) band_rebuild_one<K + 1>(mk, lo, hi);
+}
+__device__ __forceinline__ void band_rebuild(BandMasks &mk, uint32_t lo, uint32_t hi) { band_rebuild_one<0>(mk, lo, hi); }
+__device__ __forceinline__ void band_toggle(BandMasks &mk, uint32_t p)
+{
+    const uint64_t bit = 1ull << ((p >> 4) & 63u);
+    switch (p & 15u) {
+    case 0: mk.m0 ^= bit; break;
+    case 1: mk.m1 ^= bit; break;
+    case 2: mk.m2 ^= bit; break;
+    case 3: mk.m3 ^= bit; break;
+    case 4: mk.m4 ^= bit; break;
+    case 5: mk.m5 ^= bit; break;
+    case 6: mk.m6 ^= bit; break;
+    case 7: mk.m7 ^= bit; break;
+    case 8: mk.m8 ^= bit; break;
+    case 9: mk.m9 ^= bit; break;
+    case 10: mk.m10 ^= bit; break;
+    case 11: mk.m11 ^= bit; break;
+    case 12: mk.m12 ^= bit; break;
+    case 13: mk.m13 ^= bit; break;
+    case 14: mk.m14 ^= bit; break;
+    default: mk.m15 ^= bit; break;
+    }
+}
+// bits 0,2,..,2(n-1)
+__device__ __forceinline__ uint32_t pair_mask(int n)
+{
+    n = n < 0 ? 0 : n;
+    return n >= 16 ? 0x55555555u : (((1u << (2 * n)) - 1u) & 0x55555555u);
+}
+// per-lane pair-space mask of the cells of block `blk` that are inside [lo,hi)
+__device__ __forceinline__ uint32_t band_pairs(uint32_t lo, uint32_t hi, int blk)
+{
+    const int p0 = blk * 16;
+    return pair_mask((int)hi - p0) & ~pair_mask((int)lo - p0);
+}
+__device__ __forceinline__ void load_block_labels(const int32_t *labx, int blk, int (&la)[8])
+{
+    const int4 *p = reinterpret_cast<const int4 *>(labx + (size_t)blk * 8);
+    const int4 a = p[0], b = p[1];
+    la[0] = a.x; la[1] = a.y; la[2] = a.z; la[3] = a.w;
+    la[4] = b.x; la[5] = b.y; la[6] = b.z; la[7] = b.w;
+}
+
+// one blank cell (even position): moves {0,1,3} below max_move; move 2 is vetoed (align.py:80-81)
+template <int M>
+__device__ __forceinline__ void cell_blank(float a0, float a1, float a3, float e, float &m, uint32_t &word)
+{
+    const float c0 = a0 + e;
+    if constexpr (M == 1) {
+        m = c0;
+        word <<= 2;
+    } else {
+        const float c1 = a1 + e;
+        const uint64_t g1 = fgt(c1, c0);
+        const float m01 = __builtin_fmaxf(c0, c1);
+        if constexpr (M <= 3) {
+            m = m01;
+            word = shl1_in(word << 1, g1);
+        } else {
+            const float c3 = a3 + e;
+            const uint64_t g3 = fgt(c3, m01);
+            m = __builtin_fmaxf(m01, c3);
+            word = shl1_in(shl1_in(word, g3), g3 | g1);  // 3 = 0b11, 1 = 0b01
+        }
+    }
+}
+// one label cell (odd position): moves 0..M-1; move 2 vetoed when the label VALUE is 0
+template <int M, bool ZL>
+__device__ __forceinline__ void cell_label(float a0, float a1, float a2, float a3, float e, float veto,
+                                           float &m, uint32_t &word)
+{
+    const float c0 = a0 + e;
+    if constexpr (M == 1) {
+        m = c0;
+        word <<= 2;
+    } else {
+        const float c1 = a1 + e;
+        const uint64_t g1 = fgt(c1, c0);
+        const float m01 = __builtin_fmaxf(c0, c1);
+        if constexpr (M == 2) {
+            m = m01;
+            word = shl1_in(word << 1, g1);
+        } else {
+            float c2 = a2 + e;
+            if constexpr (ZL) c2 = __builtin_fminf(c2, veto);  // veto = -inf where label == 0, else +inf
+            if constexpr (M == 3) {
+                const uint64_t g2 = fgt(c2, m01);
+                m = __builtin_fmaxf(m01, c2);
+                word = shl1_in(shl1_in(word, g2), ~g2 & g1);  // 2 = 0b10
+            } else {
+                const float c3 = a3 + e;
+                const uint64_t g3 = fgt(c3, c2);
+                const float m23 = __builtin_fmaxf(c2, c3);
+                const uint64_t g23 = fgt(m23, m01);
+                m = __builtin_fmaxf(m01, m23);
+                word = shl1_in(shl1_in(word, g23), (g23 & g3) | (~g23 & g1));
+            }
+        }
+    }
+}
+
+// cells 15..0 of one frame, in place (descending k: cell k reads the old k-1..k-3)
+template <int M, bool ZL, int K>
+__device__ __forceinline__ void frame_cells(float (&sc)[16], float h1, float h2, float h3, const float (&ec)[8],
+                                            const float (&vz)[8], float e0, BandMasks &mk, float NINF, uint32_t &word)
+{
+    const float a0 = sc[K];
+    const float a1 = K >= 1 ? sc[K >= 1 ? K - 1 : 0] : h1;
+    const float a2 = K >= 2 ? sc[K >= 2 ? K - 2 : 0] : (K == 1 ? h1 : h2);
+    const float a3 = K >= 3 ? sc[K >= 3 ? K - 3 : 0] : (K == 2 ? h1 : (K == 1 ? h2 : h3));
+    float m;
+    if constexpr (K & 1)
+        cell_label<M, ZL>(a0, a1, a2, a3, ec[K >> 1], vz[K >> 1], m, word);
+    else
+        cell_blank<M>(a0, a1, a3, e0, m, word);
+    sc[K] = select_by_mask(NINF, m, mk.at<K>());
+    if constexpr (K > 0) frame_cells<M, ZL, K - 1>(sc, h1, h2, h3, ec, vz, e0, mk, NINF, word);
+}
+
+// ---------------------------------------------------------------------------------------
+// forward DP, one wavefront per lattice
+// ---------------------------------------------------------------------------------------
+template <int M, bool ZL>
+__device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
+{
+    constexpr int D = kRowDepth;
+    const int lane = threadIdx.x;
+    // descriptor fields are wave-uniform; say so explicitly so that everything derived from
+    // them (band limits, lane masks) is kept on the scalar unit
+    const uint32_t T = (uint32_t)__builtin_amdgcn_readfirstlane(d.T);
+    const uint32_t L = (uint32_t)__builtin_amdgcn_readfirstlane(d.L);
+    const uint32_t B = (uint32_t)__builtin_amdgcn_readfirstlane(d.beam);
+    const uint32_t halfB = B >> 1;
+    const uint32_t dq = L / T, dr = L % T;
+    const float NINF = ninf();
+
+    float sc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sc[k] = NINF;
+    if (lane == 0) sc[0] = 0.0f;            // virtual state before frame 0 (align.py:57-58)
+    uint32_t pres2 = lane == 0 ? 1u : 0u;   // bit 2k: cell k holds a live state
+    bool pend_reset = false;                // wave-uniform: some lane was re-labelled for this frame
+    bool reset_lane = false;                // per lane: this lane was re-labelled
+
+    int blk = lane;                         // block of 16 positions this lane currently owns
+    uint32_t blo = 0;                       // lo >> 4
+    int la[8];
+    float vz[8];
+    const int32_t *labx = d.labx;
+    load_block_labels(labx, blk, la);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vz[i] = (ZL && la[i] == 0) ? NINF : __builtin_inff();
+
+    uint32_t q = 0, rem = 0;                // floor(L*t/T) and its remainder, advanced per frame
+    uint32_t lo = 0, hi = B < L ? B : L;    // band of frame 0
+    BandMasks mk;
+    band_rebuild(mk, lo, hi);
+    uint32_t band2 = band_pairs(lo, hi, blk);
+
+    const bool vlane = lane < d.V;
+    const float *lp = d.lp + (vlane ? lane : 0);
+    const size_t ld = (size_t)d.ld;
+    float rows[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const uint32_t tt = (uint32_t)i < T ? (uint32_t)i : T - 1;
+        const float v = lp[(size_t)tt * ld];
+        rows[i] = vlane ? v : NINF;
+    }
+    float ec[8], e0c;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ec[i] = bperm(la[i], rows[0]);
+    e0c = first_lane(rows[0]);
+
+    uint32_t *bp = reinterpret_cast<uint32_t *>(d.bp) + lane;
+
+    for (uint32_t tb = 0; tb < T; tb += D) {
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) {
+            const uint32_t t = tb + dd;
+            if (t < T) {
+                // A. band of frame t+1; re-label the lanes whose block has been passed by lo
+                uint32_t nq = q + dq, nrem = rem + dr;
+                if (nrem >= T) { nrem -= T; ++nq; }
+                uint32_t nlo = nq > halfB ? nq - halfB : 0u;
+                uint32_t nhi = (L - nlo < B) ? L : nlo + B;
+                if (t + 1 == T) { nlo = lo; nhi = hi; }  // no frame T: keep the last band and labels
+                bool relabeled = false;
+                bool relabel_lane = false;
+                if ((nlo >> 4) != blo) {
+                    blo = nlo >> 4;
+                    const int nb = (int)blo + ((lane - (int)blo) & 63);
+                    if (nb != blk) {
+                        blk = nb;
+                        load_block_labels(labx, blk, la);
+                        relabel_lane = true;
+                    }
+                    relabeled = true;
+                }
+                // B. emissions of frame t+1 (independent of the scores: issued one frame ahead)
+                float en[8], e0n;
+                {
+                    const float rn = rows[(dd + 1) % D];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) en[i] = bperm(la[i], rn);
+                    e0n = first_lane(rn);
+                }
+                // C. frame t
+                float h1 = wave_ror1(sc[15]), h2 = wave_ror1(sc[14]), h3 = wave_ror1(sc[13]);
+                if (pend_reset) {
+                    // a lane re-labelled for this frame holds scores of its OLD block: its new
+                    // positions were not live in frame t-1.  Its left halo is valid unless the left
+                    // neighbour was re-labelled in the same step (then nobody held those positions).
+                    const bool left_reset = __builtin_amdgcn_update_dpp(0, (int)reset_lane, 0x13C, 0xF, 0xF, false) != 0;
+                    const bool kill = reset_lane && left_reset;
+                    h1 = kill ? NINF : h1;
+                    h2 = kill ? NINF : h2;
+                    h3 = kill ? NINF : h3;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) sc[k] = reset_lane ? NINF : sc[k];
+                    pres2 = reset_lane ? 0u : pres2;
+                }
+                uint32_t word = 0;
+                frame_cells<M, ZL, 15>(sc, h1, h2, h3, ec, vz, e0c, mk, NINF, word);
+                bp[(size_t)t * 64] = word;
+                // live <=> in band and (moved in from a live state, or stayed on a live state)
+                pres2 = (pres2 | ((word | (word >> 1)) & 0x55555555u)) & band2;
+                // prefetch the row of frame t+D
+                {
+                    const uint32_t tt = t + D < T ? t + D : T - 1;
+                    const float v = lp[(size_t)tt * ld];
+                    rows[dd] = vlane ? v : NINF;
+                }
+                // D. lane masks of frame t+1
+                if (nlo != lo || nhi != hi) {
+                    if ((nhi - hi) + (nlo - lo) <= 6u) {
+                        for (uint32_t p = hi; p < nhi; ++p) band_toggle(mk, p);
+                        for (uint32_t p = lo; p < nlo; ++p) band_toggle(mk, p);
+                    } else {
+                        band_rebuild(mk, nlo, nhi);
+                    }
+                    band2 = band_pairs(nlo, nhi, blk);
+                    lo = nlo;
+                    hi = nhi;
+                    if (ZL && relabeled) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) vz[i] = la[i] == 0 ? NINF : __builtin_inff();
+                    }
+                }
+                q = nq;
+                rem = nrem;
+                pend_reset = relabeled;
+                reset_lane = relabel_lane;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ec[i] = en[i];
+                e0c = e0n;
+            }
+        }
+    }
+
+    // terminal state: the HIGHEST live position of frame T-1 (align.py:99-101)
+    int best = -1;
+    if (pres2) best = blk * 16 + ((31 - __clz((int)pres2)) >> 1);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const int o = __shfl_xor(best, off);
+        best = o > best ? o : best;
+    }
+    int32_t *m = meta_of(meta, d.idx);
+    if (best < 0) {
+        if (lane == 0) {
+            m[1] = -1;
+            atomicMin(&m[0], kStatusEmptyBeam);
+        }
+    } else if ((best >> 4) == blk) {
+        float v = sc[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v = (best & 15) == k ? sc[k] : v;
+        m[1] = best;
+        m[3] = __builtin_bit_cast(int32_t, v);
+    }
+}
+
+template <int M>
+__global__ __launch_bounds__(64, 4) void forward_w16_kernel(const Lattice *__restrict__ lats, int32_t *meta)
+{
+    const Lattice &d = lats[blockIdx.x];
+    const int zl = __builtin_amdgcn_readfirstlane(meta_of(meta, d.idx)[2] & 1);
+    if (zl)
+        forward_w16<M, true>(d, meta);
+    else
+        forward_w16<M, false>(d, meta);
+}
+
+// ---------------------------------------------------------------------------------------
+// backtrace + output gathers, one wavefront per lattice
+// 32 frames of back-pointer rows sit in 32 VGPRs (row f across the 64 lanes); the walk is a
+// scalar chain: v_readlane(row[f], lane(p)) -> 2 bits -> p -= bits.  The next 32 rows are
+// loaded while the current ones are walked.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void bt_load(uint32_t (&r)[32], const uint32_t *bp, int t0, int n)
+{
+#pragma unroll
+    for (int f = 0; f < 32; ++f) r[f] = f < n ? bp[(size_t)(t0 + f) * 64] : 0u;
+}
+__device__ __forceinline__ void bt_walk(const uint32_t (&r)[32], int n, int &p, int &pathv)
+{
+#pragma unroll
+    for (int f = 31; f >= 0; --f) {
+        if (f < n) {
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)r[f], (p >> 4) & 63);
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(pathv) : "s"(p), "i"(f));  // pathv[lane f] = p
+            p -= (int)((w >> ((p & 15) * 2)) & 3u);
+        }
+    }
+}
+__device__ __forceinline__ void bt_emit(const Lattice &d, int t0, int n, int pathv, int lane)
+{
+    if (lane < n) {
+        const int t = t0 + lane;
+        const int pp = pathv;
+        const int lab = (pp & 1) ? (d.labx[pp >> 1] >> 2) : 0;
+        d.path[t] = pp;
+        d.lab_out[t] = lab;
+        d.sc_out[t] = d.lp[(size_t)t * (size_t)d.ld + lab];
+    }
+}
+
+__global__ __launch_bounds__(64) void backtrace_w16_kernel(const Lattice *__restrict__ lats, const int32_t *meta)
+{
+    const Lattice &d = lats[blockIdx.x];
+    const int lane = threadIdx.x;
+    int p = __builtin_amdgcn_readfirstlane(meta[4 * (size_t)d.idx + 1]);
+    if (p < 0) return;  // empty beam: status already set by the forward kernel
+    const uint32_t *bp = reinterpret_cast<const uint32_t *>(d.bp) + lane;
+    int thi = d.T;
+    uint32_t ra[32], rb[32];
+    int t0a = thi > 32 ? thi - 32 : 0, na = thi - t0a;
+    bt_load(ra, bp, t0a, na);
+    while (true) {
+        // chunk A is loaded; prefetch chunk B = the 32 frames before it
+        const int t0b = t0a > 32 ? t0a - 32 : 0, nb = t0a - t0b;
+        if (nb > 0) bt_load(rb, bp, t0b, nb);
+        int pathv = 0;
+        bt_walk(ra, na, p, pathv);
+        bt_emit(d, t0a, na, pathv, lane);
+        if (nb <= 0) break;
+        const int t0c = t0b > 32 ? t0b - 32 : 0, nc = t0b - t0c;
+        if (nc > 0) bt_load(ra, bp, t0c, nc);
+        pathv = 0;
+        bt_walk(rb, nb, p, pathv);
+        bt_emit(d, t0b, nb, pathv, lane);
+        if (nc <= 0) break;
+        t0a = t0c;
+        na = nc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// generic path: any beam width, any V, max_move <= 255.  One 256-thread workgroup per
+// lattice, score columns double-buffered in global memory (L2-resident), one byte of
+// back-pointer per band cell.  Correctness path for argument ranges the w16 layout does
+// not cover (beam > 1009 on a longer transcript, V > 64, max_move > 4); not tuned.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void forward_generic_kernel(const Lattice *__restrict__ lats, int32_t *meta)
+{
+    const Lattice &d = lats[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int64_t T = d.T, L = d.L, B = d.beam;
+    const int M = d.max_move;
+    const int64_t W = d.W;
+    float *scA = d.col, *scB = d.col + L;
+    uint8_t *prA = reinterpret_cast<uint8_t *>(d.col + 2 * L), *prB = prA + L;
+    uint8_t *bp = reinterpret_cast<uint8_t *>(d.bp);
+    for (int64_t p = tid; p < L; p += 256) { prA[p] = 0; prB[p] = 0; }
+    __syncthreads();
+    if (tid == 0) { scA[0] = 0.0f; prA[0] = 1; }
+    __syncthreads();
+    int64_t plo = 0, phi = 1;
+    for (int64_t t = 0; t < T; ++t) {
+        int64_t lo = (L * t) / T - B / 2;  // host guarantees L, T < 2^31
+        lo = lo < 0 ? 0 : lo;
+        const int64_t hi = (L - lo < B) ? L : lo + B;
+        const float *row = d.lp + (size_t)t * (size_t)d.ld;
+        for (int64_t p = lo + tid; p < hi; p += 256) {
+            const int lab = (p & 1) ? (d.labx[p >> 1] >> 2) : 0;
+            const float e = row[lab];
+            float best = ninf();
+            int bj = 0;
+            for (int j = 0; j < M; ++j) {
+                const int64_t u = p - j;
+                if (u < 0) break;
+                const bool pres = (u >= plo && u < phi) ? prA[u] != 0 : false;
+                float c = pres ? scA[u] + e : ninf();
+                if (j > 0 && (j & 1) == 0 && lab == 0) c = ninf();
+                if (j == 0 || c > best) { best = c; bj = j; }
+            }
+            const int64_t ub = p - bj;
+            prB[p] = (ub >= plo && ub < phi) ? prA[ub] : 0;
+            scB[p] = best;
+            bp[(size_t)t * (size_t)W + (size_t)(p - lo)] = (uint8_t)bj;
+        }
+        __syncthreads();
+        { float *x = scA; scA = scB; scB = x; }
+        { uint8_t *x = prA; prA = prB; prB = x; }
+        plo = lo;
+        phi = hi;
+    }
+    // highest live position of the last frame
+    __shared__ int64_t s_best;
+    if (tid == 0) s_best = -1;
+    __syncthreads();
+    int64_t mine = -1;
+    for (int64_t p = plo + tid; p < phi; p += 256)
+        if (prA[p]) mine = p;
+    if (mine >= 0) atomicMax((long long *)&s_best, (long long)mine);
+    __syncthreads();
+    if (tid == 0) {
+        int32_t *m = meta_of(meta, d.idx);
+        if (s_best < 0) {
+            m[1] = -1;
+            atomicMin(&m[0], kStatusEmptyBeam);
+        } else {
+            m[1] = (int32_t)s_best;
+            m[3] = __builtin_bit_cast(int32_t, scA[s_best]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void backtrace_generic_kernel(const Lattice *__restrict__ lats, const int32_t *meta)
+{
+    const Lattice &d = lats[blockIdx.x];
+    const int lane = threadIdx.x;
+    int64_t p = meta[4 * (size_t)d.idx + 1];
+    if (p < 0) return;
+    const int64_t T = d.T, L = d.L, B = d.beam, W = d.W;
+    const uint8_t *bp = reinterpret_cast<const uint8_t *>(d.bp);
+    if (lane == 0) {
+        for (int64_t t = T - 1; t >= 0; --t) {
+            int64_t lo = (L * t) / T - B / 2;  // host guarantees L, T < 2^31
+            lo = lo < 0 ? 0 : lo;
+            d.path[t] = (int32_t)p;
+            p -= bp[(size_t)t * (size_t)W + (size_t)(p - lo)];
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int64_t t = lane; t < T; t += 64) {
+        const int pp = d.path[t];
+        const int lab = (pp & 1) ? (d.labx[pp >> 1] >> 2) : 0;
+        d.lab_out[t] = lab;
+        d.sc_out[t] = d.lp[(size_t)t * (size_t)d.ld + lab];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// mean-subtracted log-softmax (align.py:116-117), one wavefront per row
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float x)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+    return x;
+}
+__global__ __launch_bounds__(256) void log_softmax_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                          int64_t T, int V, int64_t ld_in, int64_t ld_out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const float *x = in + (size_t)row * (size_t)ld_in;
+    float *y = out + (size_t)row * (size_t)ld_out;
+    float s = 0.0f;
+    for (int c = lane; c < V; c += 64) s += x[c];
+    const float mean = wave_sum(s) / (float)V;
+    float z = 0.0f;
+    for (int c = lane; c < V; c += 64) z += expf(x[c] - mean);
+    const float lz = logf(wave_sum(z));
+    for (int c = lane; c < V; c += 64) y[c] = (x[c] - mean) - lz;
+}
+
+// ---------------------------------------------------------------------------------------
+// hash generator (bit-identical to oracle/ctc_oracle.c kao_hash_*)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t idx)
+{
+    uint64_t z = (seed * 0x9E3779B97F4A7C15ull + idx + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void hash_logprobs_kernel(float *lp, int64_t T, int V, int64_t ld, uint64_t seed)
+{
+    const int64_t n = T * (int64_t)V;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = i / V;
+        const int c = (int)(i - t * V);
+        const uint64_t h = mix64(seed, (uint64_t)i);
+        lp[(size_t)t * (size_t)ld + c] = -8.0f * ((float)(h >> 40) * (1.0f / 16777216.0f));
+    }
+}
+__global__ __launch_bounds__(256) void hash_labels_kernel(int32_t *labels, int64_t S, int V, uint64_t seed)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < S; k += (int64_t)gridDim.x * blockDim.x)
+        labels[k] = (int32_t)(1 + mix64(seed ^ 0x4C4142454C53ull, (uint64_t)k) % (uint64_t)(V - 1));
+}
+
+}  // namespace ka

@@ -1,0 +1,247 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the reference-made goldens and
+the CPU oracle.  Integer outputs bit-exact; float outputs bit-exact too (they are gathers of
+the inputs; the cumulative score is the same float32 add chain) — north_star allows 1e-4."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from golden_util import g1_cases, g2_cases, g3_case, g4, sha
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ka():
+    import torch
+    assert torch.cuda.is_available()
+    import kokoro_align_amd as ka
+    assert os.path.exists(ka.library_path()), "HIP library not built"
+    return ka
+
+
+def _same(got, want):
+    return all(np.array_equal(np.asarray(g).view(np.int32), np.asarray(w).view(np.int32)) for g, w in zip(got, want))
+
+
+def test_g1_tiny_single_calls(ka):
+    for c in g1_cases():
+        if c["status"] == 1:
+            with pytest.raises(ValueError):
+                ka.ctc_best_path(c["lp"], c["labels"], beam_size=c["beam"], max_move=c["max_move"], verbose=False)
+            continue
+        got = ka.ctc_best_path(c["lp"], c["labels"], beam_size=c["beam"], max_move=c["max_move"], verbose=False)
+        assert _same(got, (c["path"], c["best_labels"], c["best_scores"])), (c["idx"], c["T"], c["S"], c["beam"], c["max_move"])
+
+
+def test_g1_tiny_batched(ka):
+    cases = g1_cases()
+    groups = {}
+    for c in cases:
+        groups.setdefault((c["V"], c["beam"], c["max_move"]), []).append(c)
+    n = 0
+    for (V, beam, mm), cs in groups.items():
+        res, status, total = ka.ctc_best_path_batch([c["lp"] for c in cs], [c["labels"] for c in cs], beam, mm,
+                                                    return_status=True)
+        for c, r, st in zip(cs, res, status):
+            if c["status"] == 1:
+                assert st == -1, c["idx"]
+            else:
+                assert st == 0, c["idx"]
+                assert _same(r, (c["path"], c["best_labels"], c["best_scores"])), c["idx"]
+                n += 1
+    assert n > 150
+
+
+def test_g2_medium(ka):
+    for c in g2_cases():
+        lp = O.hash_logprobs(c["T"], c["V"], c["seed"])
+        labels = O.hash_labels(c["S"], c["V"], c["seed"])
+        p, l, s = ka.ctc_best_path(lp, labels, beam_size=c["beam"], max_move=c["max_move"], verbose=False)
+        assert np.array_equal(p, c["path"]), c["idx"]
+        assert sha(l) == c["sha_labels"] and sha(s) == c["sha_scores"], c["idx"]
+
+
+def test_g3_cfg2_device_generated(ka):
+    """BASELINE configs[1]: inputs generated in HBM by the HIP hash generator, path vs the reference's."""
+    import torch
+    c = g3_case()
+    T, V, S = c["T"], c["V"], c["S"]
+    lib = ka.load_library()
+    lp = torch.empty((T, V), dtype=torch.float32, device="cuda")
+    lab = torch.empty(S, dtype=torch.int32, device="cuda")
+    assert lib.ka_hash_logprobs_f32(lp.data_ptr(), T, V, V, c["seed"], None) == 0
+    assert lib.ka_hash_labels_i32(lab.data_ptr(), S, V, c["seed"], None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(lp.cpu().numpy(), O.hash_logprobs(T, V, c["seed"]))
+    assert np.array_equal(lab.cpu().numpy(), O.hash_labels(S, V, c["seed"]))
+    (p, l, s), = ka.ctc_best_path_device([lp], [lab], beam_size=c["beam"], max_move=c["max_move"])
+    assert np.array_equal(p.cpu().numpy(), c["path"])
+    assert sha(l.cpu().numpy()) == c["sha_labels"] and sha(s.cpu().numpy()) == c["sha_scores"]
+
+
+def _rand_case(rng, T, V, S, zero_labels=False, ties=False, ninf=False):
+    lp = rng.standard_normal((T, V)).astype(np.float32)
+    lp = lp - np.log(np.sum(np.exp(lp), axis=-1, keepdims=True))
+    if ties:
+        lp = (np.round(lp * 2) / 2).astype(np.float32)
+    if ninf:
+        lp = np.where(rng.random((T, V)) < 0.1, -np.inf, lp).astype(np.float32)
+    labels = rng.integers(0 if zero_labels else 1, V, size=S).astype(np.int32)
+    return lp, labels
+
+
+@pytest.mark.parametrize("mm", [1, 2, 3, 4])
+def test_random_vs_oracle_fast_path(ka, mm):
+    rng = np.random.default_rng(100 + mm)
+    lps, labs, want = [], [], []
+    for i in range(24):
+        V = int(rng.choice([5, 39, 64]))
+        S = int(rng.integers(1, 1500))
+        T = int(rng.integers(max(1, (2 * S + 1) // 3), 3 * S + 50))
+        lp, labels = _rand_case(rng, T, V, S, zero_labels=(i % 3 == 0), ties=(i % 4 == 1), ninf=(i % 6 == 5))
+        try:
+            w = O.ctc_best_path_c(lp, labels, 1000, mm, return_total=True)
+        except ValueError:
+            w = None
+        lps.append(lp); labs.append(labels); want.append(w)
+    by_v = {}
+    for i, lp in enumerate(lps):
+        by_v.setdefault(lp.shape[1], []).append(i)
+    for V, idxs in by_v.items():
+        res, status, total = ka.ctc_best_path_batch([lps[i] for i in idxs], [labs[i] for i in idxs], 1000, mm,
+                                                    return_status=True)
+        for j, i in enumerate(idxs):
+            if want[i] is None:
+                assert status[j] == -1
+            else:
+                assert status[j] == 0
+                assert _same(res[j], want[i][:3]), (i, lps[i].shape, labs[i].shape)
+                assert np.float32(total[j]).view(np.int32) == np.float32(want[i][3]).view(np.int32)
+
+
+def test_band_edges_and_long_transcripts(ka):
+    """lo/hi sliding over many 16-position blocks, wrap of the 1024 slots, several beams."""
+    rng = np.random.default_rng(7)
+    for T, V, S, beam in [(9000, 39, 4000, 1000), (7000, 64, 3000, 1009), (6000, 39, 2500, 333),
+                          (4000, 20, 5500, 1000), (2000, 39, 2900, 800), (12000, 39, 1500, 1000)]:
+        lp, labels = _rand_case(rng, T, V, S)
+        try:
+            want = O.ctc_best_path_c(lp, labels, beam, 4)
+        except ValueError:
+            with pytest.raises(ValueError):
+                ka.ctc_best_path(lp, labels, beam_size=beam, verbose=False)
+            continue
+        got = ka.ctc_best_path(lp, labels, beam_size=beam, verbose=False)
+        assert _same(got, want), (T, V, S, beam)
+
+
+def test_degenerate_jumps(ka):
+    """L/T far above 3: the band outruns every state (ValueError), or T tiny."""
+    rng = np.random.default_rng(8)
+    for T, V, S, beam in [(10, 39, 5000, 1000), (3, 39, 5000, 1000), (40, 8, 2000, 1000), (100, 8, 1700, 1000),
+                          (2, 5, 600, 1000), (700, 8, 1100, 50)]:
+        lp, labels = _rand_case(rng, T, V, S)
+        try:
+            want = O.ctc_best_path_c(lp, labels, beam, 4)
+        except ValueError:
+            with pytest.raises(ValueError):
+                ka.ctc_best_path(lp, labels, beam_size=beam, verbose=False)
+            continue
+        got = ka.ctc_best_path(lp, labels, beam_size=beam, verbose=False)
+        assert _same(got, want), (T, V, S, beam)
+
+
+def test_generic_path(ka):
+    """Arguments outside the w16 layout: V > 64, beam > 1009 on a long transcript, max_move > 4."""
+    rng = np.random.default_rng(9)
+    for T, V, S, beam, mm in [(600, 100, 300, 1000, 4), (900, 39, 1200, 2000, 4), (500, 39, 200, 1000, 6),
+                              (800, 130, 900, 5000, 5), (300, 39, 700, 100000, 4)]:
+        lp, labels = _rand_case(rng, T, V, S, zero_labels=True)
+        try:
+            want = O.ctc_best_path_c(lp, labels, beam, mm)
+        except ValueError:
+            with pytest.raises(ValueError):
+                ka.ctc_best_path(lp, labels, beam_size=beam, max_move=mm, verbose=False)
+            continue
+        got = ka.ctc_best_path(lp, labels, beam_size=beam, max_move=mm, verbose=False)
+        assert _same(got, want), (T, V, S, beam, mm)
+
+
+def test_errors(ka):
+    lp = np.zeros((10, 5), np.float32)
+    with pytest.raises(IndexError):
+        ka.ctc_best_path(lp, np.array([1, 7], np.int32), verbose=False)      # label >= V
+    with pytest.raises(IndexError):
+        ka.ctc_best_path(np.zeros((0, 5), np.float32), np.array([1], np.int32), verbose=False)  # T = 0
+    with pytest.raises(ValueError):
+        ka.ctc_best_path(lp, np.array([1, 2], np.int32), beam_size=0, verbose=False)   # empty band
+    p, l, s = ka.ctc_best_path(lp, np.zeros(0, np.int32), verbose=False)     # S = 0: all blank
+    assert np.array_equal(p, np.zeros(10, np.int32))
+
+
+def test_strided_device_input(ka):
+    import torch
+    rng = np.random.default_rng(10)
+    lp, labels = _rand_case(rng, 700, 39, 300)
+    want = O.ctc_best_path_c(lp, labels, 1000, 4)
+    wide = torch.zeros((700, 64), dtype=torch.float32, device="cuda")
+    wide[:, :39] = torch.from_numpy(lp).cuda()
+    view = wide[:, :39]                       # row stride 64, V = 39
+    (p, l, s), = ka.ctc_best_path_device([view], [labels])
+    assert _same((p.cpu().numpy(), l.cpu().numpy(), s.cpu().numpy()), want)
+
+
+def test_log_softmax_kernel(ka):
+    import torch
+    rng = np.random.default_rng(11)
+    for V in (39, 64, 100):
+        x = (rng.standard_normal((513, V)) * 3).astype(np.float32)
+        c = x - np.mean(x, axis=-1, keepdims=True)
+        want = c - np.log(np.sum(np.exp(c), axis=-1, keepdims=True))
+        got = ka.log_softmax_device(torch.from_numpy(x).cuda()).cpu().numpy()
+        assert np.allclose(got, want, rtol=0, atol=2e-6 * max(1.0, np.abs(want).max()))
+
+
+def test_file_round_trip_matches_reference(ka):
+    """best_path() -> align() on files, against the text the reference wrote (g4)."""
+    g = g4()
+    with tempfile.TemporaryDirectory() as td:
+        voca = os.path.join(td, "x.voca.txt")
+        with open(voca, "wt") as f:
+            f.write(g["voca_txt"])
+        for name in ("rt_a", "rt_b", "rt_c"):
+            rt = g[name]
+            T, segs = rt["T"], rt["segments"]
+            logits = O.hash_logprobs(T, 39, rt["logits_seed"]) + np.float32(4.0)
+            labels = np.array(g["read_transcript"], np.int64)
+            S = labels.shape[0]
+            ext = np.zeros(2 * S + 1, np.int64); ext[1::2] = labels
+            logits[np.arange(T), ext[np.arange(T) * (2 * S + 1) // T]] += 4.0
+            assert sha(logits) == rt["logits_sha"]
+            lf, mf, bf = (os.path.join(td, f"{name}.{e}.npz") for e in ("logits", "mfcc", "best_path"))
+            np.savez(lf, indices=np.array(segs, np.int32), data=logits)
+            np.savez(mf, indices=np.array(segs, np.int32), data=np.zeros((T, 1), np.float32))
+            ka.best_path(lf, voca, bf)
+            with np.load(bf) as f:
+                assert {k: str(f[k].dtype) for k in f.files} == rt["dtypes"]
+                assert f["best_path"].tolist() == rt["best_path"]
+                assert f["best_labels"].tolist() == rt["best_labels"]
+                assert np.allclose(f["best_scores"], np.array(rt["best_scores"], np.float32), atol=1e-4)
+            for rw in (True, False):
+                af = os.path.join(td, f"{name}.{int(rw)}.align.txt")
+                ka.align(bf, mf, voca, af, rw)
+                got = open(af).read().splitlines()
+                want = rt[f"align_txt_{int(rw)}"].splitlines()
+                assert len(got) == len(want)
+                for gl, wl in zip(got, want):
+                    gp, wp = gl.split("|"), wl.split("|")
+                    assert gp[:5] == wp[:5]
+                    assert abs(float(gp[5]) - float(wp[5])) < 1e-3 and abs(float(gp[6]) - float(wp[6])) < 1e-3
+            # device log-softmax variant gives the same path
+            bf2 = os.path.join(td, f"{name}.dev.best_path.npz")
+            ka.best_path(lf, voca, bf2, device_softmax=True)
+            with np.load(bf2) as f:
+                assert f["best_path"].tolist() == rt["best_path"]
