@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the CTC forced-alignment hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--lattices B]
+
+Workload (BASELINE.json configs[1]): synthetic log-probs T=50000 x V=64, S=5000 phonemes
+(L=10001), beam_size=1000, max_move=4.  One "step" = one pass of the hot path (label prep +
+forward DP + backtrace + output gathers) over a batch of B independent lattices of that
+shape, each with its own hash-generated inputs, already resident in HBM.  Metric = aligned
+audio frames per second, whole job (all ranks).  N>1: one process per GPU (launched by
+torch.distributed.run), lattices sharded across ranks, no data-path collective (weak scaling).
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+T, V, S, BEAM, MAX_MOVE = 50000, 64, 5000, 1000, 4
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_frame():
+    """4V (log-prob row read once) + Wbar/4 (2-bit back-pointer per band cell,
+    written once) for the forward DP kernel; + 0.25 (back-pointer read) + 12 (three 4-byte
+    outputs) for the backtrace.  Wbar from the band definition (align.py:64-65)."""
+    L = 2 * S + 1
+    cells = 0
+    for t in range(T):
+        lo = max(0, L * t // T - BEAM // 2)
+        cells += min(lo + BEAM, L) - lo
+    wbar = cells / T
+    fwd = 4.0 * V + wbar / 4.0
+    return fwd, fwd + 12.25, wbar
+
+
+def cpu_baseline(sample_frames):
+    """The reference's CPU path cannot travel; time the oracle's per-frame NumPy port (same
+    NumPy work per frame as kokoro_align/align.py:62-93) on a bounded sample of the same
+    workload, single thread like the reference."""
+    from oracle import oracle as O
+    lp = O.hash_logprobs(T, V, 0)
+    labels = O.hash_labels(S, V, 0)
+    t0 = time.perf_counter()
+    O.ctc_best_path_numpy(lp, labels, BEAM, MAX_MOVE, frame_limit=sample_frames)
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    O.ctc_best_path_c(lp, labels, BEAM, MAX_MOVE)
+    dt_c = time.perf_counter() - t1
+    return {
+        "value": sample_frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+        "sample": f"first {sample_frames} of the {T} frames of one cfg2 lattice (forward DP incl. band/compaction), "
+                  f"NumPy per-frame port, {dt:.1f} s; host has {os.cpu_count()} logical CPUs",
+        "c_oracle_frames_per_s": T / dt_c,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--lattices", type=int, default=int(os.environ.get("KA_BENCH_LATTICES", "2048")),
+                    help="lattices per GPU per step")
+    ap.add_argument("--cpu-sample-frames", type=int, default=30000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import kokoro_align_amd as ka
+    from kokoro_align_amd.align import DeviceBatch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+        # start-up collective of the pipeline: broadcast of the acoustic-model weights (2.3 MB)
+        from kokoro_align_amd.sharding import broadcast_model_weights
+        broadcast_model_weights(dev)
+
+    lib = ka.load_library()
+    B = args.lattices
+    # ---- synthetic inputs, generated in HBM (hash generator == oracle's, so any lattice can be re-checked on CPU)
+    lps = torch.empty((B, T, V), dtype=torch.float32, device=dev)
+    labs = torch.empty((B, S), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    for i in range(B):
+        seed = rank * 1000003 + i
+        assert lib.ka_hash_logprobs_f32(lps[i].data_ptr(), T, V, V, seed, stream) == 0
+        assert lib.ka_hash_labels_i32(labs[i].data_ptr(), S, V, seed, stream) == 0
+    torch.cuda.synchronize()
+    batch = DeviceBatch([lps[i] for i in range(B)], [labs[i] for i in range(B)], BEAM, MAX_MOVE)
+    batch.engine.reserve(batch.workspace_bytes() + (1 << 20))
+    batch.engine.set_profiling(True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.run()
+    barrier()
+    fwd_ms, bt_ms, prep_ms = [], [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.run()                      # enqueue + stream sync + per-lattice status check
+        k = batch.engine.last_kernel_ms()
+        fwd_ms.append(k["forward"]); bt_ms.append(k["backtrace"]); prep_ms.append(k["prep"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # parity spot check on the timed outputs (lattice 0 of rank 0 is the golden cfg2 lattice)
+    ok = True
+    if rank == 0:
+        from tests.golden_util import g3_case
+        g3 = g3_case()
+        ok = bool(np.array_equal(batch.path[0].cpu().numpy(), g3["path"]))
+        ends = torch.stack([p[-1] for p in batch.path[: min(B, 64)]]).cpu().numpy()
+        ok = ok and bool((ends == 2 * S).all())
+
+    # single-lattice latency (the serial T-chain; one wavefront busy on the whole chip)
+    single = None
+    if rank == 0:
+        one = DeviceBatch([lps[0]], [labs[0]], BEAM, MAX_MOVE)
+        one.engine.set_profiling(True)
+        one.run()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            one.run()
+        dt1 = (time.perf_counter() - t1) / 3
+        k1 = one.engine.last_kernel_ms()
+        single = {"frames_per_s": T / dt1, "ms": dt1 * 1e3, "forward_ms": k1["forward"], "backtrace_ms": k1["backtrace"]}
+
+    if rank == 0:
+        frames_per_step = B * T * world
+        value = frames_per_step * args.steps / elapsed
+        fwd_b, job_b, wbar = algorithmic_bytes_per_frame()
+        fwd_s = float(np.mean(fwd_ms)) * 1e-3
+        achieved = B * T * fwd_b / fwd_s / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tf):
+            try:
+                with open(tf) as f:
+                    pt = json.load(f)
+                if int(pt.get("lattices", -1)) == B:
+                    traffic = pt.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "aligned audio-frames/sec (whole node), 50k x 5k lattice",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic (hash-generated log-probs and labels, in HBM)",
+            "config": {"workload": f"cfg2: T={T} x V={V} log-probs, S={S} phonemes (L={2 * S + 1}), beam_size={BEAM}, "
+                                   f"max_move={MAX_MOVE}; batch of {B} independent lattices per GPU per step",
+                       "lattices_per_gpu": B, "frames_per_step": frames_per_step, "parallelism": f"lattice-sharded x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "forward_w16_kernel<4>", "kernel_ms": fwd_s * 1e3,
+                         "algorithmic_bytes_per_frame": fwd_b, "mean_band_width": wbar},
+            "kernels_ms": {"prep": float(np.mean(prep_ms)), "forward": float(np.mean(fwd_ms)),
+                           "backtrace": float(np.mean(bt_ms))},
+            "job_bytes_per_frame": job_b,
+            "single_lattice": single,
+            "parity_spot_check": ok,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_frames)
+            out["speedup_vs_cpu_numpy_1core"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

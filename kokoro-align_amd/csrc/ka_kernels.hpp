@@ -31,6 +31,19 @@
 
 namespace ka {
 
+// Pointers read from a descriptor in memory are generic ("flat") to the compiler; everything
+// here lives in HBM, so say so: global_load/global_store instead of flat_* (which also tie
+// up lgkmcnt).
+#define KA_GLOBAL __attribute__((address_space(1)))
+typedef KA_GLOBAL const float *gcf32_t;
+typedef KA_GLOBAL float *gf32_t;
+typedef KA_GLOBAL const int32_t *gci32_t;
+typedef KA_GLOBAL int32_t *gi32_t;
+typedef KA_GLOBAL const uint32_t *gcu32_t;
+typedef KA_GLOBAL uint32_t *gu32_t;
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef KA_GLOBAL const v4i_t *gci4_t;
+
 constexpr int kStatusOk = 0;
 constexpr int kStatusEmptyBeam = -1;
 constexpr int kStatusBadLabel = -5;
@@ -116,6 +129,22 @@ __device__ __forceinline__ float first_lane(float x)
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
 }
 
+// Log-prob row loads are issued from inline asm so that hipcc does not track them: with a store
+// and a load of different kinds in flight it would wait vmcnt(0) before every row use, draining
+// the whole prefetch ring each frame.  The matching counted wait is row_wait<N>() below.
+__device__ __forceinline__ float row_load(uint32_t lane_byte_off, const void *row_base /* wave-uniform */)
+{
+    float r;
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(r) : "v"(lane_byte_off), "s"(row_base) : "memory");
+    return r;
+}
+// wait until at most N younger vector-memory operations are outstanding, then release `r`
+template <int N>
+__device__ __forceinline__ void row_wait(float &r)
+{
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "i"(N) : "memory");
+}
+
 // Lane masks of the band: m<k> has bit ((p>>4)&63) set for every p in [lo,hi) with p&15 == k.
 // A struct of named members (not an array): members can only be addressed with constant
 // indices, so the masks stay in SGPR pairs (an array indexed through the switch below is
@@ -189,10 +218,10 @@ __device__ __forceinline__ uint32_t band_pairs(uint32_t lo, uint32_t hi, int blk
     const int p0 = blk * 16;
     return pair_mask((int)hi - p0) & ~pair_mask((int)lo - p0);
 }
-__device__ __forceinline__ void load_block_labels(const int32_t *labx, int blk, int (&la)[8])
+__device__ __forceinline__ void load_block_labels(gci32_t labx, int blk, int (&la)[8])
 {
-    const int4 *p = reinterpret_cast<const int4 *>(labx + (size_t)blk * 8);
-    const int4 a = p[0], b = p[1];
+    gci4_t p = (gci4_t)(labx + (size_t)blk * 8);
+    const v4i_t a = p[0], b = p[1];
     la[0] = a.x; la[1] = a.y; la[2] = a.z; la[3] = a.w;
     la[4] = b.x; la[5] = b.y; la[6] = b.z; la[7] = b.w;
 }
@@ -302,7 +331,7 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
     uint32_t blo = 0;                       // lo >> 4
     int la[8];
     float vz[8];
-    const int32_t *labx = d.labx;
+    gci32_t labx = (gci32_t)d.labx;
     load_block_labels(labx, blk, la);
 #pragma unroll
     for (int i = 0; i < 8; ++i) vz[i] = (ZL && la[i] == 0) ? NINF : __builtin_inff();
@@ -313,22 +342,25 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
     band_rebuild(mk, lo, hi);
     uint32_t band2 = band_pairs(lo, hi, blk);
 
-    const bool vlane = lane < d.V;
-    const float *lp = d.lp + (vlane ? lane : 0);
-    const size_t ld = (size_t)d.ld;
+    // lanes >= V read column 0 (a valid address); their value is never selected (labels < V)
+    const uint32_t lane_off = (lane < d.V ? (uint32_t)lane : 0u) * 4u;
+    const char *lp = reinterpret_cast<const char *>(d.lp);
+    const size_t ld = (size_t)d.ld * 4;  // row pitch in bytes
     float rows[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
         const uint32_t tt = (uint32_t)i < T ? (uint32_t)i : T - 1;
-        const float v = lp[(size_t)tt * ld];
-        rows[i] = vlane ? v : NINF;
+        rows[i] = row_load(lane_off, lp + (size_t)tt * ld);
     }
-    float ec[8], e0c;
+    row_wait<D - 1>(rows[0]);
+    // emissions, double-buffered by frame parity: e[t&1] is used by frame t while e[(t+1)&1]
+    // is being gathered for frame t+1
+    float e[2][8], e0[2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) ec[i] = bperm(la[i], rows[0]);
-    e0c = first_lane(rows[0]);
+    for (int i = 0; i < 8; ++i) e[0][i] = bperm(la[i], rows[0]);
+    e0[0] = first_lane(rows[0]);
 
-    uint32_t *bp = reinterpret_cast<uint32_t *>(d.bp) + lane;
+    gu32_t bp = (gu32_t)d.bp + lane;
 
     for (uint32_t tb = 0; tb < T; tb += D) {
 #pragma unroll
@@ -338,7 +370,8 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                 // A. band of frame t+1; re-label the lanes whose block has been passed by lo
                 uint32_t nq = q + dq, nrem = rem + dr;
                 if (nrem >= T) { nrem -= T; ++nq; }
-                uint32_t nlo = nq > halfB ? nq - halfB : 0u;
+                const int32_t dlo = (int32_t)nq - (int32_t)halfB;  // signed on purpose: s_max_i32, not a VALU usubsat
+                uint32_t nlo = (uint32_t)(dlo > 0 ? dlo : 0);
                 uint32_t nhi = (L - nlo < B) ? L : nlo + B;
                 if (t + 1 == T) { nlo = lo; nhi = hi; }  // no frame T: keep the last band and labels
                 bool relabeled = false;
@@ -350,20 +383,28 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                         blk = nb;
                         load_block_labels(labx, blk, la);
                         relabel_lane = true;
+                        // consume the loads HERE: otherwise the wait for them lands at the merge
+                        // point as an every-frame s_waitcnt vmcnt(0) that also drains the row
+                        // prefetches and the back-pointer stores
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(la[i]));
                     }
                     relabeled = true;
                 }
                 // B. emissions of frame t+1 (independent of the scores: issued one frame ahead)
-                float en[8], e0n;
                 {
+                    // row t+1 was issued D-1 frames ago; since then (D-2) frames each issued one
+                    // back-pointer store and one row load (rare label reloads only add younger ops)
+                    row_wait<2 * (D - 2)>(rows[(dd + 1) % D]);
                     const float rn = rows[(dd + 1) % D];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) en[i] = bperm(la[i], rn);
-                    e0n = first_lane(rn);
+                    for (int i = 0; i < 8; ++i) e[(dd + 1) & 1][i] = bperm(la[i], rn);
+                    e0[(dd + 1) & 1] = first_lane(rn);
                 }
                 // C. frame t
                 float h1 = wave_ror1(sc[15]), h2 = wave_ror1(sc[14]), h3 = wave_ror1(sc[13]);
-                if (pend_reset) {
+                if (__builtin_expect(pend_reset, 0)) {
+                    asm volatile("" ::: "memory");  // keep this rare block a real branch (no if-conversion)
                     // a lane re-labelled for this frame holds scores of its OLD block: its new
                     // positions were not live in frame t-1.  Its left halo is valid unless the left
                     // neighbour was re-labelled in the same step (then nobody held those positions).
@@ -377,15 +418,14 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                     pres2 = reset_lane ? 0u : pres2;
                 }
                 uint32_t word = 0;
-                frame_cells<M, ZL, 15>(sc, h1, h2, h3, ec, vz, e0c, mk, NINF, word);
+                frame_cells<M, ZL, 15>(sc, h1, h2, h3, e[dd & 1], vz, e0[dd & 1], mk, NINF, word);
                 bp[(size_t)t * 64] = word;
                 // live <=> in band and (moved in from a live state, or stayed on a live state)
                 pres2 = (pres2 | ((word | (word >> 1)) & 0x55555555u)) & band2;
                 // prefetch the row of frame t+D
                 {
                     const uint32_t tt = t + D < T ? t + D : T - 1;
-                    const float v = lp[(size_t)tt * ld];
-                    rows[dd] = vlane ? v : NINF;
+                    rows[dd] = row_load(lane_off, lp + (size_t)tt * ld);
                 }
                 // D. lane masks of frame t+1
                 if (nlo != lo || nhi != hi) {
@@ -407,9 +447,6 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                 rem = nrem;
                 pend_reset = relabeled;
                 reset_lane = relabel_lane;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) ec[i] = en[i];
-                e0c = e0n;
             }
         }
     }
@@ -454,7 +491,7 @@ __global__ __launch_bounds__(64, 4) void forward_w16_kernel(const Lattice *__res
 // scalar chain: v_readlane(row[f], lane(p)) -> 2 bits -> p -= bits.  The next 32 rows are
 // loaded while the current ones are walked.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void bt_load(uint32_t (&r)[32], const uint32_t *bp, int t0, int n)
+__device__ __forceinline__ void bt_load(uint32_t (&r)[32], gcu32_t bp, int t0, int n)
 {
 #pragma unroll
     for (int f = 0; f < 32; ++f) r[f] = f < n ? bp[(size_t)(t0 + f) * 64] : 0u;
@@ -475,10 +512,10 @@ __device__ __forceinline__ void bt_emit(const Lattice &d, int t0, int n, int pat
     if (lane < n) {
         const int t = t0 + lane;
         const int pp = pathv;
-        const int lab = (pp & 1) ? (d.labx[pp >> 1] >> 2) : 0;
-        d.path[t] = pp;
-        d.lab_out[t] = lab;
-        d.sc_out[t] = d.lp[(size_t)t * (size_t)d.ld + lab];
+        const int lab = (pp & 1) ? (((gci32_t)d.labx)[pp >> 1] >> 2) : 0;
+        ((gi32_t)d.path)[t] = pp;
+        ((gi32_t)d.lab_out)[t] = lab;
+        ((gf32_t)d.sc_out)[t] = ((gcf32_t)d.lp)[(size_t)t * (size_t)d.ld + lab];
     }
 }
 
@@ -488,7 +525,7 @@ __global__ __launch_bounds__(64) void backtrace_w16_kernel(const Lattice *__rest
     const int lane = threadIdx.x;
     int p = __builtin_amdgcn_readfirstlane(meta[4 * (size_t)d.idx + 1]);
     if (p < 0) return;  // empty beam: status already set by the forward kernel
-    const uint32_t *bp = reinterpret_cast<const uint32_t *>(d.bp) + lane;
+    gcu32_t bp = (gcu32_t)d.bp + lane;
     int thi = d.T;
     uint32_t ra[32], rb[32];
     int t0a = thi > 32 ? thi - 32 : 0, na = thi - t0a;
