@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256) void log_softmax_kernel(const float *__restric
 }
 
 // ---------------------------------------------------------------------------------------
-// hash generator (bit-identical to oracle/ctc_oracle.c kao_hash_*)
+// hash generator of synthetic inputs (definition: include/kokoro_align_amd.h)
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t idx)
 {

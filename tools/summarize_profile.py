@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Condense a scripts_prof.sh output directory (rocprofv3 CSVs) into profiles/<tag>_*.
+
+    python tools/summarize_profile.py gpurun_out/prof_<tag> <tag> <lattices>
+
+Writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats summary, verbatim),
+profiles/<tag>_summary.json (per-kernel dispatch durations split by grid size, PMC counters per
+dispatch with the gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md §HBM) and refreshes
+profiles/pmc_traffic.json, which bench.py reads for roofline.traffic.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, tag, lattices = sys.argv[1], sys.argv[2], int(sys.argv[3])
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out_dir = os.path.join(root, "profiles")
+os.makedirs(out_dir, exist_ok=True)
+
+
+def one(pattern):
+    files = glob.glob(os.path.join(src, pattern))
+    return files[0] if files else None
+
+
+summary = {"tag": tag, "lattices_per_launch": lattices, "source": "rocprofv3 --kernel-trace --stats / --pmc (separate passes)"}
+ks = one("stats/*/*kernel_stats.csv")
+if ks:
+    shutil.copy(ks, os.path.join(out_dir, f"{tag}_kernel_stats.csv"))
+kt = one("stats/*/*kernel_trace.csv")
+if kt:
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(kt)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if "hash_" in name or "at::" in name or "rocclr" in name:
+            continue
+        grid = int(r["Grid_Size"]) if "Grid_Size" in r else int(r.get("Grid_Size_X", 0))
+        per[(name, grid)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    summary["dispatch_ms"] = [
+        {"kernel": k, "grid_threads": g, "calls": len(v), "avg_ms": sum(v) / len(v), "min_ms": min(v), "max_ms": max(v)}
+        for (k, g), v in sorted(per.items())]
+pmc = {}
+for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    f = one(f"{name}/*/*counter_collection.csv")
+    if not f:
+        continue
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if "hash_" in k or "at::" in k or "rocclr" in k:
+            continue
+        key = (k, int(r["Grid_Size"]))
+        pmc.setdefault(key, collections.defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
+rows = []
+for (k, g), c in sorted(pmc.items()):
+    rows.append({"kernel": k, "grid_threads": g, "counters_per_dispatch": {n: sum(v) / len(v) for n, v in c.items()}})
+summary["pmc"] = rows
+# HBM traffic of the forward kernel's batch launch: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950
+# FETCH_SIZE reports half of a coalesced streaming read (MI355X_MICROARCH.md §HBM) -> x2.
+for r in rows:
+    if "forward_w16" in r["kernel"] and r["grid_threads"] == lattices * 64:
+        c = r["counters_per_dispatch"]
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            read_b = c["FETCH_SIZE"] * 1024 * 2
+            write_b = c["WRITE_SIZE"] * 1024
+            summary["forward_hbm_bytes_per_launch"] = {"read_corrected_x2": read_b, "write": write_b, "total": read_b + write_b}
+            with open(os.path.join(out_dir, "pmc_traffic.json"), "wt") as f:
+                json.dump({"lattices": lattices, "hbm_bytes_per_launch": read_b + write_b, "tag": tag,
+                           "note": "FETCH_SIZE*1024*2 + WRITE_SIZE*1024 of forward_w16_kernel<4>, one launch"}, f)
+bj = os.path.join(src, "bench_under_rocprof.json")
+if os.path.exists(bj):
+    try:
+        summary["bench_line_under_rocprof"] = json.loads(open(bj).read().strip().splitlines()[-1])
+    except Exception:
+        pass
+with open(os.path.join(out_dir, f"{tag}_summary.json"), "wt") as f:
+    json.dump(summary, f, indent=1)
+print(json.dumps(summary.get("dispatch_ms", []), indent=1))
+print(summary.get("forward_hbm_bytes_per_launch"))
