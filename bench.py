@@ -117,12 +117,12 @@ def main():
     for _ in range(args.warmup):
         batch.run()
     barrier()
-    fwd_ms, bt_ms, prep_ms = [], [], []
+    fwd_ms, bt_ms, prep_ms, ga_ms = [], [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         batch.run()                      # enqueue + stream sync + per-lattice status check
         k = batch.engine.last_kernel_ms()
-        fwd_ms.append(k["forward"]); bt_ms.append(k["backtrace"]); prep_ms.append(k["prep"])
+        fwd_ms.append(k["forward"]); bt_ms.append(k["backtrace"]); prep_ms.append(k["prep"]); ga_ms.append(k["gather"])
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -150,7 +150,7 @@ def main():
             one.run()
         dt1 = (time.perf_counter() - t1) / 3
         k1 = one.engine.last_kernel_ms()
-        single = {"frames_per_s": T / dt1, "ms": dt1 * 1e3, "forward_ms": k1["forward"], "backtrace_ms": k1["backtrace"]}
+        single = {"frames_per_s": T / dt1, "ms": dt1 * 1e3, "forward_ms": k1["forward"], "backtrace_ms": k1["backtrace"], "gather_ms": k1["gather"]}
 
     if rank == 0:
         frames_per_step = B * T * world
@@ -181,7 +181,7 @@ def main():
                          "kernel": "forward_w16_kernel<4>", "kernel_ms": fwd_s * 1e3,
                          "algorithmic_bytes_per_frame": fwd_b, "mean_band_width": wbar},
             "kernels_ms": {"prep": float(np.mean(prep_ms)), "forward": float(np.mean(fwd_ms)),
-                           "backtrace": float(np.mean(bt_ms))},
+                           "backtrace": float(np.mean(bt_ms)), "gather": float(np.mean(ga_ms))},
             "job_bytes_per_frame": job_b,
             "single_lattice": single,
             "parity_spot_check": ok,

@@ -98,10 +98,10 @@ int ka_ctc_best_path_batch_enqueue_f32(ka_engine *e, int32_t n, const float *con
 int ka_batch_finish(ka_engine *e, float *total_score, int32_t *status);
 
 /* Per-kernel timing of the LAST enqueued batch, measured with HIP events recorded on the
- * launch stream: ms[0] label prep, ms[1] forward DP, ms[2] backtrace + gathers.
- * Enable before the call; costs two events per kernel. */
+ * launch stream: ms[0] label prep, ms[1] forward DP, ms[2] backtrace walk, ms[3] output
+ * gathers (best_labels / best_scores).  Enable before the call; costs one event per kernel. */
 int ka_engine_set_profiling(ka_engine *e, int32_t on);
-int ka_engine_last_kernel_ms(ka_engine *e, float ms[3]);
+int ka_engine_last_kernel_ms(ka_engine *e, float ms[4]);
 
 /*
  * Mean-subtracted log-softmax of kokoro_align/align.py:116-117 on device:

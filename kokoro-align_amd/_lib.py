@@ -141,9 +141,9 @@ class Engine:
         check(self.lib.ka_engine_set_profiling(self.handle, int(bool(on))), "ka_engine_set_profiling")
 
     def last_kernel_ms(self):
-        ms = (ctypes.c_float * 3)()
+        ms = (ctypes.c_float * 4)()
         check(self.lib.ka_engine_last_kernel_ms(self.handle, ms), "ka_engine_last_kernel_ms")
-        return {"prep": ms[0], "forward": ms[1], "backtrace": ms[2]}
+        return {"prep": ms[0], "forward": ms[1], "backtrace": ms[2], "gather": ms[3]}
 
     def reserve(self, nbytes):
         check(self.lib.ka_engine_reserve(self.handle, int(nbytes)), "ka_engine_reserve")

@@ -73,7 +73,7 @@ struct ka_engine {
     size_t ws_bytes = 0;
     char *pin = nullptr;
     size_t pin_bytes = 0;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool profiling = false;
     bool have_times = false;
     // last enqueued batch
@@ -118,7 +118,8 @@ int ensure_pin(ka_engine *e, size_t bytes)
 template <int M>
 void launch_forward(const ka::Lattice *d_lats, int n, int32_t *d_meta, hipStream_t s)
 {
-    hipLaunchKernelGGL(ka::forward_w16_kernel<M>, dim3(n), dim3(64), 0, s, d_lats, d_meta);
+    hipLaunchKernelGGL((ka::forward_w16_kernel<M, false>), dim3(n), dim3(64), 0, s, d_lats, d_meta);
+    hipLaunchKernelGGL((ka::forward_w16_kernel<M, true>), dim3(n), dim3(64), 0, s, d_lats, d_meta);
 }
 
 }  // namespace
@@ -139,7 +140,7 @@ int ka_engine_create(int32_t device, ka_engine **out)
     KA_HIP(hipSetDevice(device));
     ka_engine *e = new ka_engine();
     e->device = device;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 5; ++i) {
         hipError_t er = hipEventCreate(&e->ev[i]);
         if (er != hipSuccess) {
             delete e;
@@ -157,7 +158,7 @@ void ka_engine_destroy(ka_engine *e)
     (void)hipDeviceSynchronize();
     if (e->ws) (void)hipFree(e->ws);
     if (e->pin) (void)hipHostFree(e->pin);
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 5; ++i)
         if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
     delete e;
 }
@@ -190,11 +191,11 @@ int ka_engine_set_profiling(ka_engine *e, int32_t on)
     return KA_OK;
 }
 
-int ka_engine_last_kernel_ms(ka_engine *e, float ms[3])
+int ka_engine_last_kernel_ms(ka_engine *e, float ms[4])
 {
     if (!e || !ms) return fail(KA_ERR_BAD_ARGS, "engine or ms is NULL");
     if (!e->have_times) return fail(KA_ERR_BAD_ARGS, "no profiled batch has been finished");
-    for (int i = 0; i < 3; ++i) KA_HIP(hipEventElapsedTime(&ms[i], e->ev[i], e->ev[i + 1]));
+    for (int i = 0; i < 4; ++i) KA_HIP(hipEventElapsedTime(&ms[i], e->ev[i], e->ev[i + 1]));
     return KA_OK;
 }
 
@@ -336,6 +337,16 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
     if (n > n_fast)
         hipLaunchKernelGGL(ka::backtrace_generic_kernel, dim3(n - n_fast), dim3(64), 0, stream, d_lats + n_fast, d_meta);
     if (e->profiling) KA_HIP(hipEventRecord(e->ev[3], stream));
+    {
+        int64_t t_max = 1;
+        for (int32_t i = 0; i < n; ++i) t_max = std::max<int64_t>(t_max, sh[i].T);
+        const unsigned gx = (unsigned)((t_max + 1023) / 1024);
+        for (int32_t y0 = 0; y0 < n; y0 += 65535) {   // grid.y limit
+            const unsigned gy = (unsigned)std::min<int32_t>(65535, n - y0);
+            hipLaunchKernelGGL(ka::gather_outputs_kernel, dim3(gx, gy), dim3(256), 0, stream, d_lats + y0, d_meta);
+        }
+    }
+    if (e->profiling) KA_HIP(hipEventRecord(e->ev[4], stream));
     KA_HIP(hipGetLastError());
 
     // ---- copy out ----

@@ -226,27 +226,32 @@ __device__ __forceinline__ void load_block_labels(gci32_t labx, int blk, int (&l
     la[4] = b.x; la[5] = b.y; la[6] = b.z; la[7] = b.w;
 }
 
-// one blank cell (even position): moves {0,1,3} below max_move; move 2 is vetoed (align.py:80-81)
+// 64-bit lane mask of (a == b), ordered compare
+__device__ __forceinline__ uint64_t feq(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 1 /*FCMP_OEQ*/); }
+
+// Cell update.  m = max over the allowed moves (one v_max3 [+ v_max]); the back-pointer is the
+// FIRST move whose candidate equals m (np.argmax semantics, align.py:83) - found with equality
+// compares against m, whose lane masks are combined on the scalar unit.
+// Back-pointer code stored per cell (2 bits, decoded by bp_decode() in the backtrace):
+//   blank cell (moves {0,1,3}):  hi = (c0==m), lo = (c1==m)            -> 0 if hi, else 1 if lo, else 3
+//   label cell (moves {0,1,2,3}): hi = e0|e1,  lo = e0 | (e2 & ~e1)    -> (1,1)=0 (1,0)=1 (0,1)=2 (0,0)=3
+// one blank cell (even position): move 2 is vetoed for blanks (align.py:80-81)
 template <int M>
 __device__ __forceinline__ void cell_blank(float a0, float a1, float a3, float e, float &m, uint32_t &word)
 {
     const float c0 = a0 + e;
     if constexpr (M == 1) {
         m = c0;
-        word <<= 2;
+        word = (word << 2) | 2u;   // hi=1: move 0
     } else {
         const float c1 = a1 + e;
-        const uint64_t g1 = fgt(c1, c0);
-        const float m01 = __builtin_fmaxf(c0, c1);
         if constexpr (M <= 3) {
-            m = m01;
-            word = shl1_in(word << 1, g1);
+            m = __builtin_fmaxf(c0, c1);
         } else {
             const float c3 = a3 + e;
-            const uint64_t g3 = fgt(c3, m01);
-            m = __builtin_fmaxf(m01, c3);
-            word = shl1_in(shl1_in(word, g3), g3 | g1);  // 3 = 0b11, 1 = 0b01
+            m = __builtin_fmaxf(__builtin_fmaxf(c0, c1), c3);
         }
+        word = shl1_in(shl1_in(word, feq(c0, m)), feq(c1, m));
     }
 }
 // one label cell (odd position): moves 0..M-1; move 2 vetoed when the label VALUE is 0
@@ -257,31 +262,47 @@ __device__ __forceinline__ void cell_label(float a0, float a1, float a2, float a
     const float c0 = a0 + e;
     if constexpr (M == 1) {
         m = c0;
-        word <<= 2;
+        word = (word << 2) | 3u;   // (1,1): move 0
     } else {
         const float c1 = a1 + e;
-        const uint64_t g1 = fgt(c1, c0);
-        const float m01 = __builtin_fmaxf(c0, c1);
         if constexpr (M == 2) {
-            m = m01;
-            word = shl1_in(word << 1, g1);
+            m = __builtin_fmaxf(c0, c1);
+            const uint64_t e0 = feq(c0, m);
+            word = shl1_in((word << 1) | 1u, e0);   // hi=1 always (move < 2), lo = e0
         } else {
             float c2 = a2 + e;
             if constexpr (ZL) c2 = __builtin_fminf(c2, veto);  // veto = -inf where label == 0, else +inf
             if constexpr (M == 3) {
-                const uint64_t g2 = fgt(c2, m01);
-                m = __builtin_fmaxf(m01, c2);
-                word = shl1_in(shl1_in(word, g2), ~g2 & g1);  // 2 = 0b10
+                m = __builtin_fmaxf(__builtin_fmaxf(c0, c1), c2);
+                const uint64_t e0 = feq(c0, m), e1 = feq(c1, m);
+                // move 2 is the only one left when neither e0 nor e1: code (0,1)
+                word = shl1_in(shl1_in(word, e0 | e1), ~e1 | e0);
             } else {
                 const float c3 = a3 + e;
-                const uint64_t g3 = fgt(c3, c2);
-                const float m23 = __builtin_fmaxf(c2, c3);
-                const uint64_t g23 = fgt(m23, m01);
-                m = __builtin_fmaxf(m01, m23);
-                word = shl1_in(shl1_in(word, g23), (g23 & g3) | (~g23 & g1));
+                m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(c0, c1), c2), c3);
+                const uint64_t e0 = feq(c0, m), e1 = feq(c1, m), e2 = feq(c2, m);
+                word = shl1_in(shl1_in(word, e0 | e1), e0 | (e2 & ~e1));
             }
         }
     }
+}
+// number of positions to step back, from the 2-bit code of a cell (see cell_blank / cell_label)
+__device__ __forceinline__ int bp_decode(uint32_t code, int pos_is_label)
+{
+    const int hi = (code >> 1) & 1, lo = code & 1;
+    const int label_mv = hi ? (lo ? 0 : 1) : (lo ? 2 : 3);
+    const int blank_mv = hi ? 0 : (lo ? 1 : 3);
+    return pos_is_label ? label_mv : blank_mv;
+}
+// a cell's state is live after the frame iff it is in the band and (it moved in from a live
+// state = any move > 0, or it stayed on a live state).  "move == 0" per cell, bit-parallel on
+// the packed word (bit 2k+1 = hi, bit 2k = lo; even cells are blanks, odd cells labels):
+//   blank: move 0 <=> hi;  label: move 0 <=> hi & lo
+__device__ __forceinline__ uint32_t moved_pairs(uint32_t word)
+{
+    const uint32_t hi = (word >> 1) & 0x55555555u, lo = word & 0x55555555u;
+    const uint32_t stay = hi & (lo | 0x11111111u);   // 0x1111..: pair-bits of even cells (k = 0,2,4,..)
+    return ~stay & 0x55555555u;
 }
 
 // cells 15..0 of one frame, in place (descending k: cell k reads the old k-1..k-3)
@@ -360,7 +381,8 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
     for (int i = 0; i < 8; ++i) e[0][i] = bperm(la[i], rows[0]);
     e0[0] = first_lane(rows[0]);
 
-    gu32_t bp = (gu32_t)d.bp + lane;
+    const uint32_t *bp = reinterpret_cast<const uint32_t *>(d.bp);   // wave-uniform row base
+    const uint32_t lane_store_off = (uint32_t)lane * 4u;
 
     for (uint32_t tb = 0; tb < T; tb += D) {
 #pragma unroll
@@ -419,9 +441,10 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                 }
                 uint32_t word = 0;
                 frame_cells<M, ZL, 15>(sc, h1, h2, h3, e[dd & 1], vz, e0[dd & 1], mk, NINF, word);
-                bp[(size_t)t * 64] = word;
+                // saddr (uniform row pointer) + voffset (lane*4): no per-lane 64-bit address registers
+                asm volatile("global_store_dword %0, %1, %2" : : "v"(lane_store_off), "v"(word), "s"(bp + (size_t)t * 64) : "memory");
                 // live <=> in band and (moved in from a live state, or stayed on a live state)
-                pres2 = (pres2 | ((word | (word >> 1)) & 0x55555555u)) & band2;
+                pres2 = (pres2 | moved_pairs(word)) & band2;
                 // prefetch the row of frame t+D
                 {
                     const uint32_t tt = t + D < T ? t + D : T - 1;
@@ -474,49 +497,93 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
     }
 }
 
-template <int M>
-__global__ __launch_bounds__(64, 4) void forward_w16_kernel(const Lattice *__restrict__ lats, int32_t *meta)
+#ifndef KA_FWD_MIN_WAVES
+#define KA_FWD_MIN_WAVES 4
+#endif
+// Two kernels per max_move, launched back to back over the same lattices: ZL = the transcript
+// contains label 0 (needs the per-label veto).  A wave whose lattice belongs to the other kernel
+// exits at once.  Keeping them apart keeps the veto registers out of the common kernel.
+template <int M, bool ZL>
+__global__ __launch_bounds__(64, KA_FWD_MIN_WAVES) void forward_w16_kernel(const Lattice *__restrict__ lats, int32_t *meta)
 {
     const Lattice &d = lats[blockIdx.x];
     const int zl = __builtin_amdgcn_readfirstlane(meta_of(meta, d.idx)[2] & 1);
-    if (zl)
-        forward_w16<M, true>(d, meta);
-    else
-        forward_w16<M, false>(d, meta);
+    if ((zl != 0) != ZL) return;
+    forward_w16<M, ZL>(d, meta);
 }
 
 // ---------------------------------------------------------------------------------------
-// backtrace + output gathers, one wavefront per lattice
-// 32 frames of back-pointer rows sit in 32 VGPRs (row f across the 64 lanes); the walk is a
-// scalar chain: v_readlane(row[f], lane(p)) -> 2 bits -> p -= bits.  The next 32 rows are
-// loaded while the current ones are walked.
+// backtrace (best_path), one wavefront per lattice; outputs are gathered by gather_outputs_kernel
+//
+// The walk is a scalar chain: word = v_readlane(row, lane(p)) -> 2 bits -> p -= bits.
+// A path moves at most 3 positions per frame, so the 32 frames of a chunk only ever touch the
+// 16 blocks (lanes) below the position known one chunk earlier: instead of whole 256-B rows the
+// kernel reads a 64-B window per frame (4x less HBM traffic, the kernel is HBM-bound in batched
+// runs), laid out 4 frames x 16 dwords per VGPR, 8 VGPRs per chunk, and prefetches the next
+// chunk's window while the current chunk is walked.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void bt_load(uint32_t (&r)[32], gcu32_t bp, int t0, int n)
+constexpr int kBtChunk = 32;                 // frames per chunk
+constexpr int kBtReach = 3 * 2 * kBtChunk;   // positions a path can drop over two chunks
+
+// first block of the 16-block window that covers every position the path can take in the
+// chunk AFTER the one that is entered at position p_entry
+__device__ __forceinline__ int bt_window(int p_entry)
 {
-#pragma unroll
-    for (int f = 0; f < 32; ++f) r[f] = f < n ? bp[(size_t)(t0 + f) * 64] : 0u;
+    const int lo = p_entry - kBtReach;
+    return (lo > 0 ? lo : 0) >> 4;
 }
-__device__ __forceinline__ void bt_walk(const uint32_t (&r)[32], int n, int &p, int &pathv)
+// (possibly partial) chunk, compiler-tracked loads: used once per lattice for the tail chunk
+__device__ __forceinline__ void bt_load_guarded(uint32_t (&r)[8], gcu32_t bp_base, int t0, int n, int w0, int lane)
 {
+    const int j = lane & 15, fr = lane >> 4;
+    const int col = (w0 + j) & 63;
 #pragma unroll
-    for (int f = 31; f >= 0; --f) {
-        if (f < n) {
-            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)r[f], (p >> 4) & 63);
-            asm("v_writelane_b32 %0, %1, %2" : "+v"(pathv) : "s"(p), "i"(f));  // pathv[lane f] = p
-            p -= (int)((w >> ((p & 15) * 2)) & 3u);
+    for (int q = 0; q < 8; ++q) {
+        const int f = 4 * q + fr;
+        r[q] = f < n ? bp_base[(size_t)(t0 + f) * 64 + col] : 0u;
+    }
+}
+// full 32-frame chunk, loads issued from inline asm (not tracked by hipcc: it would drain vmcnt(0)
+// before the walk and serialise the prefetch); pair with bt_wait<N>()
+__device__ __forceinline__ void bt_load_async(uint32_t (&r)[8], const char *chunk_base /* uniform: row t0 */, int w0, int lane)
+{
+    const uint32_t voff = (uint32_t)(lane >> 4) * 256u + (uint32_t)((w0 + (lane & 15)) & 63) * 4u;
+    const char *hi = chunk_base + 4096;
+    asm volatile("global_load_dword %0, %4, %5\n\t"
+                 "global_load_dword %1, %4, %5 offset:1024\n\t"
+                 "global_load_dword %2, %4, %5 offset:2048\n\t"
+                 "global_load_dword %3, %4, %5 offset:3072"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(voff), "s"(chunk_base) : "memory");
+    asm volatile("global_load_dword %0, %4, %5\n\t"
+                 "global_load_dword %1, %4, %5 offset:1024\n\t"
+                 "global_load_dword %2, %4, %5 offset:2048\n\t"
+                 "global_load_dword %3, %4, %5 offset:3072"
+                 : "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]) : "v"(voff), "s"(hi) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void bt_wait(uint32_t (&r)[8])
+{
+    asm volatile("s_waitcnt vmcnt(%8)"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+                 : "i"(N) : "memory");
+}
+// One chunk of the walk.  q = p - 16*w0 is the position relative to the window (0..255), so the
+// dependent chain per frame is: q>>4 -> |lane group -> v_readlane -> >>2(q&15) -> &3 -> q -= bits.
+template <bool FULL>
+__device__ __forceinline__ void bt_walk(const uint32_t (&r)[8], int n, int w0, int &p, int &pathv)
+{
+    int q = p - 16 * w0;
+    const int base = 16 * w0;
+#pragma unroll
+    for (int f = kBtChunk - 1; f >= 0; --f) {
+        if (FULL || f < n) {
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)r[f >> 2], (q >> 4) | ((f & 3) * 16));
+            const int pos = q + base;
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(pathv) : "s"(pos), "i"(f));  // pathv[lane f] = position
+            q -= bp_decode(w >> ((q * 2) & 31), q & 1);   // 16*w0 is even: q has the parity of the position
         }
     }
-}
-__device__ __forceinline__ void bt_emit(const Lattice &d, int t0, int n, int pathv, int lane)
-{
-    if (lane < n) {
-        const int t = t0 + lane;
-        const int pp = pathv;
-        const int lab = (pp & 1) ? (((gci32_t)d.labx)[pp >> 1] >> 2) : 0;
-        ((gi32_t)d.path)[t] = pp;
-        ((gi32_t)d.lab_out)[t] = lab;
-        ((gf32_t)d.sc_out)[t] = ((gcf32_t)d.lp)[(size_t)t * (size_t)d.ld + lab];
-    }
+    p = q + base;
 }
 
 __global__ __launch_bounds__(64) void backtrace_w16_kernel(const Lattice *__restrict__ lats, const int32_t *meta)
@@ -525,27 +592,64 @@ __global__ __launch_bounds__(64) void backtrace_w16_kernel(const Lattice *__rest
     const int lane = threadIdx.x;
     int p = __builtin_amdgcn_readfirstlane(meta[4 * (size_t)d.idx + 1]);
     if (p < 0) return;  // empty beam: status already set by the forward kernel
-    gcu32_t bp = (gcu32_t)d.bp + lane;
-    int thi = d.T;
-    uint32_t ra[32], rb[32];
-    int t0a = thi > 32 ? thi - 32 : 0, na = thi - t0a;
-    bt_load(ra, bp, t0a, na);
-    while (true) {
-        // chunk A is loaded; prefetch chunk B = the 32 frames before it
-        const int t0b = t0a > 32 ? t0a - 32 : 0, nb = t0a - t0b;
-        if (nb > 0) bt_load(rb, bp, t0b, nb);
+    const char *bp = reinterpret_cast<const char *>(d.bp);
+    gi32_t path = (gi32_t)d.path;
+    const int T = __builtin_amdgcn_readfirstlane(d.T);
+    uint32_t cur[8], nxt[8];
+    // tail chunk [t0, T): 1..32 frames, so that every chunk below it is a full one
+    int t0 = ((T - 1) / kBtChunk) * kBtChunk;
+    int w = bt_window(p + 3 * kBtChunk);   // the tail chunk is entered at the end position itself
+    {
+        const int n = T - t0;
+        bt_load_guarded(cur, (gcu32_t)d.bp, t0, n, w, lane);
+        const int t1 = t0 > 0 ? t0 - kBtChunk : 0;
+        const int wn = bt_window(p);
+        bt_load_async(nxt, bp + (size_t)t1 * 256, wn, lane);   // (re-reads chunk 0 when there is no next chunk)
         int pathv = 0;
-        bt_walk(ra, na, p, pathv);
-        bt_emit(d, t0a, na, pathv, lane);
-        if (nb <= 0) break;
-        const int t0c = t0b > 32 ? t0b - 32 : 0, nc = t0b - t0c;
-        if (nc > 0) bt_load(ra, bp, t0c, nc);
-        pathv = 0;
-        bt_walk(rb, nb, p, pathv);
-        bt_emit(d, t0b, nb, pathv, lane);
-        if (nc <= 0) break;
-        t0a = t0c;
-        na = nc;
+        bt_walk<false>(cur, n, w, p, pathv);
+        if (lane < n) path[t0 + lane] = pathv;
+        bt_wait<1>(nxt);                    // younger than the 8 loads: the path store
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+        w = wn;
+    }
+    // full chunks.  Straight-line per iteration: the registers of the in-flight loads (nxt) are
+    // not touched by anything between their issue and bt_wait, and never cross the back-edge.
+    while (t0 > 0) {
+        t0 -= kBtChunk;                     // chunk [t0, t0+32) is in cur, window w, entered at p
+        const int t1 = t0 > 0 ? t0 - kBtChunk : 0;
+        const int wn = bt_window(p);
+        bt_load_async(nxt, bp + (size_t)t1 * 256, wn, lane);
+        int pathv = 0;
+        bt_walk<true>(cur, kBtChunk, w, p, pathv);
+        if (lane < kBtChunk) path[t0 + lane] = pathv;
+        bt_wait<1>(nxt);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+        w = wn;
+    }
+}
+
+// best_labels = lab'[best_path], best_scores[t] = lp[t, best_labels[t]]  (align.py:105-107)
+// grid: x = 1024-frame slice, y = lattice
+__global__ __launch_bounds__(256) void gather_outputs_kernel(const Lattice *__restrict__ lats, const int32_t *meta)
+{
+    const Lattice &d = lats[blockIdx.y];
+    if (meta[4 * (size_t)d.idx + 1] < 0) return;
+    const int T = d.T;
+    gci32_t path = (gci32_t)d.path;
+    gci32_t labx = (gci32_t)d.labx;
+    gcf32_t lp = (gcf32_t)d.lp;
+    const size_t ld = (size_t)d.ld;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = blockIdx.x * 1024 + i * 256 + threadIdx.x;
+        if (t < T) {
+            const int pp = path[t];
+            const int lab = (pp & 1) ? (labx[pp >> 1] >> 2) : 0;
+            ((gi32_t)d.lab_out)[t] = lab;
+            ((gf32_t)d.sc_out)[t] = lp[(size_t)t * ld + lab];
+        }
     }
 }
 
@@ -635,14 +739,6 @@ __global__ __launch_bounds__(64) void backtrace_generic_kernel(const Lattice *__
             d.path[t] = (int32_t)p;
             p -= bp[(size_t)t * (size_t)W + (size_t)(p - lo)];
         }
-    }
-    __threadfence_block();
-    __syncthreads();
-    for (int64_t t = lane; t < T; t += 64) {
-        const int pp = d.path[t];
-        const int lab = (pp & 1) ? (d.labx[pp >> 1] >> 2) : 0;
-        d.lab_out[t] = lab;
-        d.sc_out[t] = d.lp[(size_t)t * (size_t)d.ld + lab];
     }
 }
 
