@@ -39,23 +39,27 @@ def algorithmic_bytes_per_frame():
     return fwd, fwd + 12.25, wbar
 
 
-def cpu_baseline(sample_frames):
+def cpu_baseline(min_seconds):
     """The reference's CPU path cannot travel; time the oracle's per-frame NumPy port (same
     NumPy work per frame as kokoro_align/align.py:62-93) on a bounded sample of the same
     workload, single thread like the reference."""
     from oracle import oracle as O
     lp = O.hash_logprobs(T, V, 0)
     labels = O.hash_labels(S, V, 0)
-    t0 = time.perf_counter()
-    O.ctc_best_path_numpy(lp, labels, BEAM, MAX_MOVE, frame_limit=sample_frames)
-    dt = time.perf_counter() - t0
+    frames, dt = 0, 0.0
+    while dt < min_seconds:              # whole 50000-frame lattices until the sample is long enough
+        t0 = time.perf_counter()
+        O.ctc_best_path_numpy(lp, labels, BEAM, MAX_MOVE)
+        dt += time.perf_counter() - t0
+        frames += T
     t1 = time.perf_counter()
     O.ctc_best_path_c(lp, labels, BEAM, MAX_MOVE)
     dt_c = time.perf_counter() - t1
     return {
-        "value": sample_frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-        "sample": f"first {sample_frames} of the {T} frames of one cfg2 lattice (forward DP incl. band/compaction), "
-                  f"NumPy per-frame port, {dt:.1f} s; host has {os.cpu_count()} logical CPUs",
+        "value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+        "sample": f"{frames // T} x one full cfg2 lattice ({frames} frames; forward DP + backtrace + gathers), "
+                  f"NumPy per-frame port of align.py:43-109, single thread like the reference, {dt:.1f} s; "
+                  f"host has {os.cpu_count()} logical CPUs",
         "c_oracle_frames_per_s": T / dt_c,
     }
 
@@ -65,9 +69,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--lattices", type=int, default=int(os.environ.get("KA_BENCH_LATTICES", "2048")),
+    ap.add_argument("--lattices", type=int, default=int(os.environ.get("KA_BENCH_LATTICES", "8192")),
                     help="lattices per GPU per step")
-    ap.add_argument("--cpu-sample-frames", type=int, default=30000)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -96,16 +100,26 @@ def main():
     lib = ka.load_library()
     B = args.lattices
     # ---- synthetic inputs, generated in HBM (hash generator == oracle's, so any lattice can be re-checked on CPU)
-    lps = torch.empty((B, T, V), dtype=torch.float32, device=dev)
-    labs = torch.empty((B, S), dtype=torch.int32, device=dev)
+    # 8192 lattices = 8 wavefronts per SIMD = 215 GB (log-probs + back-pointers); halve on OOM.
+    while True:
+        try:
+            lps = torch.empty((B, T, V), dtype=torch.float32, device=dev)
+            labs = torch.empty((B, S), dtype=torch.int32, device=dev)
+            batch = DeviceBatch([lps[i] for i in range(B)], [labs[i] for i in range(B)], BEAM, MAX_MOVE)
+            batch.engine.reserve(batch.workspace_bytes() + (1 << 20))
+            break
+        except (RuntimeError, MemoryError) as exc:   # torch OOM or KA_ERR_NOMEM
+            if B <= 64:
+                raise
+            print(f"[bench] {B} lattices do not fit ({type(exc).__name__}); retrying with {B // 2}", file=sys.stderr)
+            lps = labs = batch = None
+            torch.cuda.empty_cache()
+            B //= 2
     stream = torch.cuda.current_stream().cuda_stream
-    for i in range(B):
-        seed = rank * 1000003 + i
-        assert lib.ka_hash_logprobs_f32(lps[i].data_ptr(), T, V, V, seed, stream) == 0
-        assert lib.ka_hash_labels_i32(labs[i].data_ptr(), S, V, seed, stream) == 0
+    seed0 = rank * 1000003            # lattice i of this rank uses seed0 + i (rank 0, i = 0 is the golden cfg2 lattice)
+    assert lib.ka_hash_logprobs_batch_f32(lps.data_ptr(), B, T, V, V, T * V, seed0, stream) == 0
+    assert lib.ka_hash_labels_batch_i32(labs.data_ptr(), B, S, V, S, seed0, stream) == 0
     torch.cuda.synchronize()
-    batch = DeviceBatch([lps[i] for i in range(B)], [labs[i] for i in range(B)], BEAM, MAX_MOVE)
-    batch.engine.reserve(batch.workspace_bytes() + (1 << 20))
     batch.engine.set_profiling(True)
 
     def barrier():
@@ -178,7 +192,7 @@ def main():
                        "lattices_per_gpu": B, "frames_per_step": frames_per_step, "parallelism": f"lattice-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "forward_w16_kernel<4>", "kernel_ms": fwd_s * 1e3,
+                         "kernel": "forward_w16_kernel<4,false>", "kernel_ms": fwd_s * 1e3,
                          "algorithmic_bytes_per_frame": fwd_b, "mean_band_width": wbar},
             "kernels_ms": {"prep": float(np.mean(prep_ms)), "forward": float(np.mean(fwd_ms)),
                            "backtrace": float(np.mean(bt_ms)), "gather": float(np.mean(ga_ms))},
@@ -187,7 +201,7 @@ def main():
             "parity_spot_check": ok,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_frames)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_seconds)
             out["speedup_vs_cpu_numpy_1core"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if dist is not None:

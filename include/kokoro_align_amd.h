@@ -117,6 +117,11 @@ int ka_log_softmax_f32(const float *logits, float *log_probs, int64_t T, int32_t
 int ka_hash_logprobs_f32(float *dev_log_probs, int64_t T, int32_t V, int64_t ld, uint64_t seed,
                          void *stream);
 int ka_hash_labels_i32(int32_t *dev_labels, int64_t S, int32_t V, uint64_t seed, void *stream);
+/* n lattices in one launch: lattice i at base + i*lattice_stride (elements) with seed0 + i */
+int ka_hash_logprobs_batch_f32(float *dev_log_probs, int32_t n, int64_t T, int32_t V, int64_t ld,
+                               int64_t lattice_stride, uint64_t seed0, void *stream);
+int ka_hash_labels_batch_i32(int32_t *dev_labels, int32_t n, int64_t S, int32_t V,
+                             int64_t lattice_stride, uint64_t seed0, void *stream);
 
 #ifdef __cplusplus
 }

@@ -432,25 +432,46 @@ int ka_log_softmax_f32(const float *logits, float *log_probs, int64_t T, int32_t
     return KA_OK;
 }
 
-int ka_hash_logprobs_f32(float *dev_log_probs, int64_t T, int32_t V, int64_t ld, uint64_t seed, void *stream)
+int ka_hash_logprobs_batch_f32(float *dev_log_probs, int32_t n, int64_t T, int32_t V, int64_t ld, int64_t lattice_stride,
+                               uint64_t seed0, void *stream)
 {
-    if (!dev_log_probs || T < 0 || V < 1 || ld < V) return fail(KA_ERR_BAD_ARGS, "ka_hash_logprobs_f32: bad arguments");
-    if (T == 0) return KA_OK;
-    const int64_t n = T * V;
-    const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 256 * 8);
-    hipLaunchKernelGGL(ka::hash_logprobs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dev_log_probs, T, V, ld, seed);
+    if (!dev_log_probs || n < 0 || T < 0 || V < 1 || ld < V || (n > 1 && lattice_stride < T * ld))
+        return fail(KA_ERR_BAD_ARGS, "ka_hash_logprobs_batch_f32: bad arguments");
+    if (T == 0 || n == 0) return KA_OK;
+    const unsigned blocks = (unsigned)std::min<int64_t>((T * V + 255) / 256, 512);
+    for (int32_t y0 = 0; y0 < n; y0 += 65535) {
+        const unsigned gy = (unsigned)std::min<int32_t>(65535, n - y0);
+        hipLaunchKernelGGL(ka::hash_logprobs_kernel, dim3(blocks, gy), dim3(256), 0, (hipStream_t)stream,
+                           dev_log_probs + (size_t)y0 * (size_t)lattice_stride, T, V, ld, seed0 + (uint64_t)y0, lattice_stride);
+    }
     KA_HIP(hipGetLastError());
     return KA_OK;
 }
 
-int ka_hash_labels_i32(int32_t *dev_labels, int64_t S, int32_t V, uint64_t seed, void *stream)
+int ka_hash_labels_batch_i32(int32_t *dev_labels, int32_t n, int64_t S, int32_t V, int64_t lattice_stride, uint64_t seed0,
+                             void *stream)
 {
-    if (!dev_labels || S < 0 || V < 2) return fail(KA_ERR_BAD_ARGS, "ka_hash_labels_i32: bad arguments");
-    if (S == 0) return KA_OK;
-    const unsigned blocks = (unsigned)std::min<int64_t>((S + 255) / 256, 1024);
-    hipLaunchKernelGGL(ka::hash_labels_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dev_labels, S, V, seed);
+    if (!dev_labels || n < 0 || S < 0 || V < 2 || (n > 1 && lattice_stride < S))
+        return fail(KA_ERR_BAD_ARGS, "ka_hash_labels_batch_i32: bad arguments");
+    if (S == 0 || n == 0) return KA_OK;
+    const unsigned blocks = (unsigned)std::min<int64_t>((S + 255) / 256, 64);
+    for (int32_t y0 = 0; y0 < n; y0 += 65535) {
+        const unsigned gy = (unsigned)std::min<int32_t>(65535, n - y0);
+        hipLaunchKernelGGL(ka::hash_labels_kernel, dim3(blocks, gy), dim3(256), 0, (hipStream_t)stream,
+                           dev_labels + (size_t)y0 * (size_t)lattice_stride, S, V, seed0 + (uint64_t)y0, lattice_stride);
+    }
     KA_HIP(hipGetLastError());
     return KA_OK;
+}
+
+int ka_hash_logprobs_f32(float *dev_log_probs, int64_t T, int32_t V, int64_t ld, uint64_t seed, void *stream)
+{
+    return ka_hash_logprobs_batch_f32(dev_log_probs, 1, T, V, ld, T * ld, seed, stream);
+}
+
+int ka_hash_labels_i32(int32_t *dev_labels, int64_t S, int32_t V, uint64_t seed, void *stream)
+{
+    return ka_hash_labels_batch_i32(dev_labels, 1, S, V, S, seed, stream);
 }
 
 }  // extern "C"

@@ -778,8 +778,12 @@ __device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t idx)
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
-__global__ __launch_bounds__(256) void hash_logprobs_kernel(float *lp, int64_t T, int V, int64_t ld, uint64_t seed)
+// blockIdx.y = lattice: lattice i lives at base + i*stride elements and uses seed + i
+__global__ __launch_bounds__(256) void hash_logprobs_kernel(float *lp0, int64_t T, int V, int64_t ld, uint64_t seed0,
+                                                            int64_t lattice_stride)
 {
+    float *lp = lp0 + (size_t)blockIdx.y * (size_t)lattice_stride;
+    const uint64_t seed = seed0 + blockIdx.y;
     const int64_t n = T * (int64_t)V;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t t = i / V;
@@ -788,8 +792,11 @@ __global__ __launch_bounds__(256) void hash_logprobs_kernel(float *lp, int64_t T
         lp[(size_t)t * (size_t)ld + c] = -8.0f * ((float)(h >> 40) * (1.0f / 16777216.0f));
     }
 }
-__global__ __launch_bounds__(256) void hash_labels_kernel(int32_t *labels, int64_t S, int V, uint64_t seed)
+__global__ __launch_bounds__(256) void hash_labels_kernel(int32_t *labels0, int64_t S, int V, uint64_t seed0,
+                                                          int64_t lattice_stride)
 {
+    int32_t *labels = labels0 + (size_t)blockIdx.y * (size_t)lattice_stride;
+    const uint64_t seed = seed0 + blockIdx.y;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < S; k += (int64_t)gridDim.x * blockDim.x)
         labels[k] = (int32_t)(1 + mix64(seed ^ 0x4C4142454C53ull, (uint64_t)k) % (uint64_t)(V - 1));
 }
