@@ -373,7 +373,10 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
         const uint32_t tt = (uint32_t)i < T ? (uint32_t)i : T - 1;
         rows[i] = row_load(lane_off, lp + (size_t)tt * ld);
     }
-    row_wait<D - 1>(rows[0]);
+    // Start-up: the counted wait inside the loop assumes the steady-state number of younger
+    // operations (2 stores + 2 loads); the first D rows have fewer behind them, so land them all.
+#pragma unroll
+    for (int i = 0; i < D; ++i) row_wait<0>(rows[i]);
     // emissions, double-buffered by frame parity: e[t&1] is used by frame t while e[(t+1)&1]
     // is being gathered for frame t+1
     float e[2][8], e0[2];

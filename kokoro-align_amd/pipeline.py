@@ -1,0 +1,241 @@
+"""Stages around the hot path, device-resident: logits producer -> log-softmax -> CTC best path
+-> align.txt -> metadata.txt.  Same files, keys and text formats as the reference, so the output
+of any stage can be consumed by the reference's next stage and vice versa.
+
+Reference stages mirrored (run_example.py:146-280 `process`, stages 4-7):
+  predict        kokoro_align/train.py:201-231   *.mfcc.npz  -> *.logits.npz + *.greed.txt
+  best_path      kokoro_align/align.py:112-124   *.logits.npz + *.voca.txt -> *.best_path.npz
+  align          kokoro_align/align.py:127-169   -> *.align.txt
+  combine_files  run_example.py:73-131           *.align.txt + *.split.txt -> <id>.metadata.txt
+Every stage is skipped when its output exists (run_example.py:227-228, :249-250, :262-263, :274-275).
+Upstream stages (Aozora text, G2P, MP3 split + MFCC) are not part of this package.
+"""
+import os
+
+import numpy as np
+
+from .align import _host_log_softmax, align as _write_align, ctc_best_path_device, log_softmax_device
+from .encoder import decode_text, encode_text, is_valid_text, merge_repeated
+
+
+# ------------------------------------------------------------------------------------------
+# IndexDataArray npz format (kokoro_align/preprocess.py:12-35): `indices` = cumulative row ends
+# (int32), `data` = all segments concatenated along axis 0
+# ------------------------------------------------------------------------------------------
+class IndexDataArray:
+    def __init__(self, file):
+        self.file = file
+        self.current = 0
+        self.indices = []
+        self.data = []
+
+    def __enter__(self):
+        return self
+
+    def write(self, data):
+        self.current += data.shape[0]
+        self.indices.append(self.current)
+        self.data.append(data)
+
+    def __exit__(self, exc_type, exc_value, traceback):
+        if exc_type is None:   # nothing is written when the producer failed (preprocess.py:27-31)
+            np.savez(self.file, indices=np.array(self.indices, dtype=np.int32),
+                     data=np.concatenate(self.data, axis=0))
+
+
+def open_index_data_for_write(file):
+    return IndexDataArray(file)
+
+
+def read_index_data(file):
+    """-> (indices int32 [n_seg], data [rows, ...])"""
+    with np.load(file) as f:
+        return f['indices'], f['data']
+
+
+def split_segments(indices, data):
+    out, start = [], 0
+    for end in indices.tolist():
+        out.append(data[start:end])
+        start = end
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# stage: predict (logits producer)
+# ------------------------------------------------------------------------------------------
+def predict(model, audio_file, output_file, text_file, device=None, batch_size=128):
+    """MFCC segments -> per-segment logits, written as the reference writes them
+    (train.py:215-231: `*.logits.npz` via IndexDataArray, `*.greed.txt` lines
+    f'{index+1}|{merge_repeated(greedy decode)}').  Returns the logits [T_file, vocab] as ONE
+    device tensor (segments concatenated, like the file's `data`) so that the DP can take it by
+    pointer without re-reading the file."""
+    import torch
+    from .model import segment_logits
+    device = device or next(model.parameters()).device
+    indices, data = read_index_data(audio_file)
+    seg_logits = segment_logits(model, split_segments(indices, data), device=device, batch_size=batch_size)
+    try:
+        with open_index_data_for_write(output_file) as out, open(text_file, 'wt') as txt:
+            for i, lg in enumerate(seg_logits):
+                greedy = torch.argmax(lg, dim=-1).cpu().numpy()
+                out.write(lg.detach().cpu().numpy().astype(np.float32))
+                txt.write(f'{i + 1}|{merge_repeated(decode_text(greedy))}\n')
+    except BaseException:
+        for f in (output_file, text_file):
+            if os.path.exists(f):
+                os.unlink(f)
+        raise
+    return torch.cat(seg_logits, dim=0) if seg_logits else torch.zeros((0, 0), device=device)
+
+
+# ------------------------------------------------------------------------------------------
+# stage: best_path for many files in one launch
+# ------------------------------------------------------------------------------------------
+def best_path_files(logits_files, voca_files, best_path_files_out, device=None, logits_on_device=None,
+                    host_softmax=False):
+    """All files of a dataset as ONE batched launch (the reference loops them, run_example.py:248-254).
+
+    ``logits_on_device`` (optional) maps a logits file name to a device tensor produced by
+    ``predict`` in this process; files not in the map are read from disk.  ``host_softmax``
+    computes align.py:116-117 with NumPy on the host (bit-identical log-probs to the
+    reference); the default runs the HIP log-softmax kernel on the device (1e-6).
+    Files whose output exists are skipped.  Returns the list of files written.
+    """
+    import torch
+    from .transcript import read_transcript
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    todo = [(lf, vf, bf) for lf, vf, bf in zip(logits_files, voca_files, best_path_files_out)
+            if not os.path.exists(bf)]
+    if not todo:
+        return []
+    lps, labs = [], []
+    for lf, vf, _ in todo:
+        if logits_on_device is not None and lf in logits_on_device:
+            logits = logits_on_device[lf]
+        else:
+            with np.load(lf) as f:
+                logits = f['data']
+        if host_softmax:
+            lg = logits.detach().cpu().numpy() if hasattr(logits, "detach") else logits
+            lps.append(torch.from_numpy(np.ascontiguousarray(_host_log_softmax(lg), np.float32)).to(dev))
+        else:
+            t = logits if hasattr(logits, "detach") else torch.from_numpy(np.ascontiguousarray(logits, np.float32))
+            lps.append(log_softmax_device(t.to(dev)))
+        labs.append(read_transcript(vf))
+    results = ctc_best_path_device(lps, labs)      # raises ValueError like the reference
+    for (_, _, bf), (p, l, s) in zip(todo, results):
+        try:
+            np.savez(bf, best_path=p.cpu().numpy(), best_labels=l.cpu().numpy(), best_scores=s.cpu().numpy())
+        except BaseException:
+            if os.path.exists(bf):
+                os.unlink(bf)
+            raise
+    return [bf for _, _, bf in todo]
+
+
+# ------------------------------------------------------------------------------------------
+# stage: metadata (run_example.py:73-131)
+# ------------------------------------------------------------------------------------------
+_NG_WORDS = ('リブリボックス', 'ボランティアについてなど', 'この録音はパブリックドメイン', 'ために録音されました')
+
+
+def _blocked_by_ng_word(text, voca):
+    """LibriVox boiler-plate or an empty line (run_example.py:84-88)."""
+    if text.strip() and voca.strip():
+        squeezed = text.replace(' ', '')
+        return any(w in squeezed for w in _NG_WORDS)
+    return True
+
+
+def _blocked_by_unknown_yomi(voca, remove_wordsep):
+    """run_example.py:97-100"""
+    if remove_wordsep and '_' in voca:
+        return True
+    return not is_valid_text(voca)
+
+
+def _blocked_by_few_matches(voca, decoded):
+    """Keep only segments where the decoded label count exceeds 70 % of the transcript's
+    (run_example.py:90-95)."""
+    n_voca = int(np.count_nonzero(encode_text(voca)))
+    n_dec = len(decoded.split())
+    return not (n_voca and n_dec and n_dec / n_voca > 0.7)
+
+
+def combine_files(dataset, align_files, audio_files, segment_files, metadata_file, remove_wordsep, verbose=True):
+    """align.txt + split.txt -> `<id>|<audio file>|<start>|<end>|<text>|<voca>` lines
+    (run_example.py:73-131).  start/end are audio sample offsets from split.txt."""
+    say = print if verbose else (lambda *a, **k: None)
+    os.makedirs(os.path.dirname(metadata_file), exist_ok=True)
+    try:
+        with open(metadata_file, 'wt') as out:
+            idx = 1
+            for align_file, audio_file, segment_file in zip(align_files, audio_files, segment_files):
+                audio_name = os.path.basename(audio_file)
+                with open(align_file, 'rt') as af, open(segment_file, 'rt') as sf:
+                    start = 0
+                    for aline, sline in zip(af, sf):
+                        _, text, voca, decoded, _, _, _ = aline.rstrip('\r\n').split('|')
+                        end, = sline.rstrip('\r\n').split('|')
+                        if _blocked_by_ng_word(text, voca):
+                            say(f'Blocking by NG word: {text}')
+                        elif _blocked_by_unknown_yomi(voca, remove_wordsep):
+                            say(f'Blocking by unknown yomi {voca}')
+                        elif _blocked_by_few_matches(voca, decoded):
+                            say('Blocking by too few match')
+                            say(f'voca:    {voca}')
+                            say(f'decoded: {decoded}')
+                        else:
+                            out.write(f'{dataset}-{idx:05d}|{audio_name}|{start}|{end}|{text}|{voca}\n')
+                            idx += 1
+                        start = end
+    except BaseException:
+        os.unlink(metadata_file)
+        raise
+
+
+# ------------------------------------------------------------------------------------------
+# stages 4-7 of run_example.process for one dataset
+# ------------------------------------------------------------------------------------------
+def _swap_ext(files, old, new):
+    return [f[:-len(old)] + new if f.endswith(old) else f for f in files]
+
+
+def process_alignment(dataset, audio_files, metadata_file, model=None, remove_wordsep=False, device=None,
+                      host_softmax=False, verbose=True):
+    """Given `<x>.mp3` names whose `<x>.mfcc.npz`, `<x>.split.txt`, `<x>.voca.txt` exist (made by the
+    reference's upstream stages), run predict -> best_path -> align -> combine_files with
+    skip-if-exists, all lattices of the dataset in one DP launch."""
+    say = print if verbose else (lambda *a, **k: None)
+    mfcc = _swap_ext(audio_files, '.mp3', '.mfcc.npz')
+    split = _swap_ext(audio_files, '.mp3', '.split.txt')
+    voca = _swap_ext(audio_files, '.mp3', '.voca.txt')
+    logits = _swap_ext(audio_files, '.mp3', '.logits.npz')
+    greed = _swap_ext(audio_files, '.mp3', '.greed.txt')
+    bpath = _swap_ext(audio_files, '.mp3', '.best_path.npz')
+    align_out = _swap_ext(audio_files, '.mp3', '.align.txt')
+    on_device = {}
+    for mf, lf, gf in zip(mfcc, logits, greed):
+        if os.path.exists(lf):
+            say(f'Skip writing {lf}')
+        else:
+            if model is None:
+                raise ValueError(f'{lf} is missing and no model was given')
+            say(f'Writing {lf}')
+            on_device[lf] = predict(model, mf, lf, gf, device=device)
+    written = best_path_files(logits, voca, bpath, device=device, logits_on_device=on_device, host_softmax=host_softmax)
+    for bf in bpath:
+        say(f'Writing {bf}' if bf in written else f'Skip writing {bf}')
+    for bf, mf, vf, af in zip(bpath, mfcc, voca, align_out):
+        if os.path.exists(af):
+            say(f'Skip writing {af}')
+        else:
+            say(f'Writing {af}')
+            _write_align(bf, mf, vf, af, remove_wordsep=remove_wordsep)
+    if os.path.exists(metadata_file):
+        say(f'Skip writing {metadata_file}')
+    else:
+        say(f'Writing {metadata_file}')
+        combine_files(dataset, align_out, audio_files, split, metadata_file, remove_wordsep, verbose=verbose)
+    return metadata_file

@@ -15,6 +15,9 @@ Fixtures
                      SHA-256 of labels/scores
   g4_text.json       encoder / transcript / VocaAligner I/O pairs and a best_path()->align()
                      file round trip (inputs embedded)
+  g5_pipeline.json   combine_files metadata filter (run_example.py:73-131) on the g4 align.txt
+                     texts + lines that hit every blocking rule; AudioToChar (hidden 8) weights,
+                     packed 3-segment input and logits (train.py:54-65, :92-95)
 
 Reference entry points exercised: kokoro_align/align.py:43 (ctc_best_path), :112 (best_path),
 :127 (align); kokoro_align/encoder.py:14-31; kokoro_align/transcript.py:13-67.
@@ -296,7 +299,67 @@ def make_g4():
     print("g4: written; aligner_len", out["aligner_len"], "S", len(out["read_transcript"]))
 
 
+def make_g5():
+    """combine_files (run_example.py:73-131) and the AudioToChar network (train.py:54-65, :92-95)."""
+    import torch
+    import run_example as rex                      # /root/reference/run_example.py (stdlib imports only)
+    from kokoro_align import train as rtrain
+
+    out = {}
+    g4 = json.load(open(os.path.join(HERE, "g4_text.json")))
+    extra = [  # hand-written align.txt lines that hit every blocking rule
+        "100|リブリ ボックス の 録音 です|r i b u r i b o q k u s u|r i b u|10|-3.5|-9.25",
+        "200||||0|0.0|-1.0",
+        "300|こころ|k o k o r o|k o k o r o|6|-1.5|-2.5",
+        "400|夏目 漱石|n a ts u m e _ s o: s e k i|n a ts u m e s o: s e k i|12|-2.0|-3.0",
+        "500|先生|s e N s e: x|s e N s e:|5|-1.0|-1.0",
+        "600|私 は|w a t a sh i w a|w a|1|-0.5|-7.0",
+        "700|その 人|s o n o h i t o|s o n o h i t|7|-0.25|-0.5",
+    ]
+    with tempfile.TemporaryDirectory() as td:
+        cases = {}
+        for rw in (True, False):
+            align_files, split_files, audio_files = [], [], []
+            for name in ("rt_a", "rt_b", "rt_c", "extra"):
+                lines = extra if name == "extra" else g4[name][f"align_txt_{int(rw)}"].splitlines()
+                af = os.path.join(td, f"{name}.{int(rw)}.align.txt")
+                sf = os.path.join(td, f"{name}.{int(rw)}.split.txt")
+                with open(af, "wt") as f:
+                    f.write("\n".join(lines) + "\n")
+                with open(sf, "wt") as f:
+                    for i in range(len(lines)):
+                        f.write(f"{(i + 1) * 22050 + 7 * i}\n")
+                align_files.append(af); split_files.append(sf); audio_files.append(f"/some/dir/{name}.mp3")
+            meta = os.path.join(td, "out", f"ds.{int(rw)}.metadata.txt")
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                rex.combine_files("ds", align_files, audio_files, split_files, meta, rw)
+            cases[str(int(rw))] = {
+                "align": [open(a).read() for a in align_files], "split": [open(s_).read() for s_ in split_files],
+                "audio_files": audio_files, "metadata": open(meta).read(), "stdout": buf.getvalue()}
+        out["combine_files"] = cases
+
+    # AudioToChar with a small hidden size (tiny fixture); weights from the reference's own init
+    torch.manual_seed(1234)
+    model = rtrain.AudioToChar(n_mfcc=40, hidden_dim=8, vocab_size=39).eval()
+    state = {k: v.numpy().tolist() for k, v in model.state_dict().items()}
+    lens = [17, 5, 29]
+    segs = [np.ascontiguousarray(hash_logprobs(n, 40, 900 + i) + np.float32(4.0)) for i, n in enumerate(lens)]
+    with torch.no_grad():
+        packed = rtrain.generate_batch_audio([torch.from_numpy(x) for x in segs])
+        logits, out_lens = model(packed)
+    out["audio_to_char"] = {
+        "params": {"n_mfcc": 40, "hidden_dim": 8, "vocab_size": 39}, "state_dict": state, "segment_lens": lens,
+        "segment_seeds": [900, 901, 902], "out_lens": out_lens.tolist(),
+        "logits": [logits[:n, j, :].numpy().tolist() for j, n in enumerate(lens)],
+        "default_param_count": int(sum(p.numel() for p in rtrain.AudioToChar(**rtrain.DEFAULT_PARAMS).parameters())),
+        "state_keys": list(rtrain.AudioToChar(**rtrain.DEFAULT_PARAMS).state_dict().keys())}
+    with open(os.path.join(HERE, "g5_pipeline.json"), "wt") as f:
+        json.dump(out, f, ensure_ascii=False)
+    print("g5: written;", len(out["combine_files"]["1"]["metadata"].splitlines()), "metadata lines (remove_wordsep=True)")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
     for w in which:
-        {"g1": make_g1, "g2": make_g2, "g3": make_g3, "g4": make_g4}[w]()
+        {"g1": make_g1, "g2": make_g2, "g3": make_g3, "g4": make_g4, "g5": make_g5}[w]()

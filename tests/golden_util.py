@@ -58,3 +58,8 @@ def g3_case():
 def g4():
     with open(os.path.join(GOLDEN, "g4_text.json")) as f:
         return json.load(f)
+
+
+def g5():
+    with open(os.path.join(GOLDEN, "g5_pipeline.json")) as f:
+        return json.load(f)

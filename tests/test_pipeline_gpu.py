@@ -1,0 +1,71 @@
+"""End-to-end device pipeline on the GPU: AudioToChar (PyTorch-ROCm) -> HIP log-softmax -> batched HIP DP
+-> align.txt -> metadata.txt, checked against the CPU oracle fed with the same logits."""
+import os
+
+import numpy as np
+import pytest
+
+from golden_util import g4, g5
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_audio_to_char_on_gpu_matches_reference(tmp_path):
+    import torch
+    from kokoro_align_amd.model import AudioToChar, segment_logits
+    a = g5()["audio_to_char"]
+    model = AudioToChar(**a["params"])
+    model.load_state_dict({k: torch.tensor(v, dtype=torch.float32) for k, v in a["state_dict"].items()})
+    model = model.cuda().eval()
+    segs = [O.hash_logprobs(n, 40, seed) + np.float32(4.0) for n, seed in zip(a["segment_lens"], a["segment_seeds"])]
+    got = segment_logits(model, segs)
+    for g, w in zip(got, a["logits"]):
+        assert g.is_cuda
+        assert np.allclose(g.cpu().numpy(), np.array(w, np.float32), atol=1e-4, rtol=0)   # MIOpen vs CPU LSTM
+
+
+def test_process_alignment_end_to_end(tmp_path):
+    import torch
+    from kokoro_align_amd import pipeline
+    from kokoro_align_amd.model import AudioToChar
+    from kokoro_align_amd.transcript import read_transcript
+    torch.manual_seed(5)
+    model = AudioToChar().cuda().eval()
+    voca_txt = g4()["voca_txt"]
+    audio_files = []
+    for i, seg_lens in enumerate([[120, 300, 90], [400, 250], [77, 88, 99, 111]]):
+        base = str(tmp_path / f"ch{i:02d}")
+        audio_files.append(base + ".mp3")
+        with pipeline.open_index_data_for_write(base + ".mfcc.npz") as w:
+            for j, n in enumerate(seg_lens):
+                w.write(O.hash_logprobs(n, 40, 50 * i + j) * np.float32(0.5) + np.float32(2.0))
+        with open(base + ".split.txt", "wt") as f:
+            for j in range(len(seg_lens)):
+                f.write(f"{(j + 1) * 40000}\n")
+        with open(base + ".voca.txt", "wt") as f:
+            f.write(voca_txt)
+    meta = str(tmp_path / "out" / "ds.metadata.txt")
+    pipeline.process_alignment("ds", audio_files, meta, model=model, remove_wordsep=False, verbose=False)
+    for af in audio_files:
+        base = af[:-4]
+        with np.load(base + ".logits.npz") as f:
+            logits, idx = f["data"], f["indices"]
+        with np.load(base + ".best_path.npz") as f:
+            got = (f["best_path"], f["best_labels"], f["best_scores"])
+            assert {k: str(f[k].dtype) for k in f.files} == {"best_path": "int32", "best_labels": "int32", "best_scores": "float32"}
+        # the DP itself must be exact given the device log-probs; re-derive them on the host (1e-6) and allow
+        # the path to differ only if the oracle on host log-probs differs too (it never should here)
+        c = logits - np.mean(logits, axis=-1, keepdims=True)
+        lp = c - np.log(np.sum(np.exp(c), axis=-1, keepdims=True))
+        want = O.ctc_best_path_c(lp, read_transcript(base + ".voca.txt"))
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        assert np.allclose(got[2], want[2], atol=1e-4)
+        lines = open(base + ".align.txt").read().splitlines()
+        assert len(lines) == len(idx) and [int(x.split("|")[0]) for x in lines] == idx.tolist()
+        assert os.path.exists(base + ".greed.txt")
+    assert os.path.exists(meta)
+    # second run: every stage is skipped (outputs exist), nothing is rewritten
+    before = {f: os.path.getmtime(f) for f in [meta] + [a[:-4] + ".best_path.npz" for a in audio_files]}
+    pipeline.process_alignment("ds", audio_files, meta, model=None, remove_wordsep=False, verbose=False)
+    assert before == {f: os.path.getmtime(f) for f in before}
