@@ -75,6 +75,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout must carry exactly ONE JSON line: native libraries (RCCL prints a version banner) write to
+    # fd 1 directly, so point fd 1 at stderr until the result is printed
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import kokoro_align_amd as ka
@@ -90,7 +96,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("KA_FORCE_DIST") == "1":   # KA_FORCE_DIST: exercise the RCCL path with one rank
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
         # start-up collective of the pipeline: broadcast of the acoustic-model weights (2.3 MB)
@@ -156,7 +162,7 @@ def main():
     # single-lattice latency (the serial T-chain; one wavefront busy on the whole chip)
     single = None
     if rank == 0:
-        one = DeviceBatch([lps[0]], [labs[0]], BEAM, MAX_MOVE)
+        one = DeviceBatch([lps[0]], [labs[0]], BEAM, MAX_MOVE)   # 1 lattice: KA_MODE_AUTO picks the 4-wavefront form
         one.engine.set_profiling(True)
         one.run()
         t1 = time.perf_counter()
@@ -203,7 +209,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_seconds)
             out["speedup_vs_cpu_numpy_1core"] = value / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()

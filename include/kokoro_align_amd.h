@@ -97,6 +97,15 @@ int ka_ctc_best_path_batch_enqueue_f32(ka_engine *e, int32_t n, const float *con
                                        float *const *best_scores, void *stream);
 int ka_batch_finish(ka_engine *e, float *total_score, int32_t *status);
 
+/* Forward-DP kernel form.  KA_MODE_WAVE: one wavefront per lattice (throughput; fills the chip from
+ * ~4096 lattices).  KA_MODE_WORKGROUP: four wavefronts per lattice with an LDS hand-off per frame
+ * (about 3x lower per-frame latency; for single files or a book's few dozen chapters).
+ * KA_MODE_AUTO (default): WORKGROUP up to 1024 lattices per call, WAVE above.  Results are identical. */
+#define KA_MODE_AUTO 0
+#define KA_MODE_WAVE 1
+#define KA_MODE_WORKGROUP 2
+int ka_engine_set_mode(ka_engine *e, int32_t mode);
+
 /* Per-kernel timing of the LAST enqueued batch, measured with HIP events recorded on the
  * launch stream: ms[0] label prep, ms[1] forward DP, ms[2] backtrace walk, ms[3] output
  * gathers (best_labels / best_scores).  Enable before the call; costs one event per kernel. */

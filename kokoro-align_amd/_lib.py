@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_PKG, "libkokoro_align_amd.so")
+_SO = os.environ.get("KA_LIBRARY") or os.path.join(_PKG, "libkokoro_align_amd.so")   # KA_LIBRARY: debug builds
 _lib = None
 
 KA_OK = 0
@@ -26,7 +26,7 @@ EXPORTS = [
     "ka_workspace_bytes", "ka_ctc_best_path_f32", "ka_ctc_best_path_batch_f32",
     "ka_ctc_best_path_batch_enqueue_f32", "ka_batch_finish", "ka_engine_set_profiling",
     "ka_engine_last_kernel_ms", "ka_log_softmax_f32", "ka_hash_logprobs_f32", "ka_hash_labels_i32",
-    "ka_hash_logprobs_batch_f32", "ka_hash_labels_batch_i32",
+    "ka_hash_logprobs_batch_f32", "ka_hash_labels_batch_i32", "ka_engine_set_mode",
 ]
 
 
@@ -81,6 +81,8 @@ def load_library():
     L.ka_ctc_best_path_batch_enqueue_f32.argtypes = batch_common + [vp]
     L.ka_batch_finish.restype = ctypes.c_int
     L.ka_batch_finish.argtypes = [vp, vp, vp]
+    L.ka_engine_set_mode.restype = ctypes.c_int
+    L.ka_engine_set_mode.argtypes = [vp, i32]
     L.ka_engine_set_profiling.restype = ctypes.c_int
     L.ka_engine_set_profiling.argtypes = [vp, i32]
     L.ka_engine_last_kernel_ms.restype = ctypes.c_int
@@ -141,6 +143,11 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    def set_mode(self, mode):
+        """'auto' | 'wave' (1 wavefront per lattice) | 'workgroup' (4 wavefronts per lattice)"""
+        code = {"auto": 0, "wave": 1, "workgroup": 2}[mode] if isinstance(mode, str) else int(mode)
+        check(self.lib.ka_engine_set_mode(self.handle, code), "ka_engine_set_mode")
 
     def set_profiling(self, on=True):
         check(self.lib.ka_engine_set_profiling(self.handle, int(bool(on))), "ka_engine_set_profiling")

@@ -33,6 +33,9 @@ int fail(int code, const std::string &msg)
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+// KA_MODE_AUTO: up to this many lattices per call use the 4-wavefront form (256 CUs x 4 lattices)
+constexpr int32_t kAutoWorkgroupMaxLattices = 1024;
+
 struct Shape {
     int64_t T, S, L, W;
     int32_t labx_len;
@@ -81,6 +84,7 @@ struct ka_engine {
     hipStream_t stream_last = nullptr;
     int32_t *h_meta = nullptr;  // pinned, 4 ints per lattice
     bool pending = false;
+    int32_t mode = KA_MODE_AUTO;
 };
 
 namespace {
@@ -116,10 +120,17 @@ int ensure_pin(ka_engine *e, size_t bytes)
 }
 
 template <int M>
-void launch_forward(const ka::Lattice *d_lats, int n, int32_t *d_meta, hipStream_t s)
+void launch_forward(const ka::Lattice *d_lats, int n, int32_t *d_meta, hipStream_t s, bool workgroup_form)
 {
-    hipLaunchKernelGGL((ka::forward_w16_kernel<M, false>), dim3(n), dim3(64), 0, s, d_lats, d_meta);
-    hipLaunchKernelGGL((ka::forward_w16_kernel<M, true>), dim3(n), dim3(64), 0, s, d_lats, d_meta);
+    // two launches over the same lattices: a lattice is taken by the kernel that matches its
+    // "transcript contains label 0" flag, the other one's waves exit at once
+    if (workgroup_form) {
+        hipLaunchKernelGGL((ka::forward_wg4_kernel<M, false>), dim3(n), dim3(256), 0, s, d_lats, d_meta);
+        hipLaunchKernelGGL((ka::forward_wg4_kernel<M, true>), dim3(n), dim3(256), 0, s, d_lats, d_meta);
+    } else {
+        hipLaunchKernelGGL((ka::forward_w16_kernel<M, false>), dim3(n), dim3(64), 0, s, d_lats, d_meta);
+        hipLaunchKernelGGL((ka::forward_w16_kernel<M, true>), dim3(n), dim3(64), 0, s, d_lats, d_meta);
+    }
 }
 
 }  // namespace
@@ -181,6 +192,15 @@ size_t ka_workspace_bytes(int32_t n, const int64_t *T, const int64_t *S, int32_t
         total += lattice_ws_bytes(sh);
     }
     return total;
+}
+
+int ka_engine_set_mode(ka_engine *e, int32_t mode)
+{
+    if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
+    if (mode != KA_MODE_AUTO && mode != KA_MODE_WAVE && mode != KA_MODE_WORKGROUP)
+        return fail(KA_ERR_BAD_ARGS, "ka_engine_set_mode: unknown mode");
+    e->mode = mode;
+    return KA_OK;
 }
 
 int ka_engine_set_profiling(ka_engine *e, int32_t on)
@@ -322,21 +342,26 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
     hipLaunchKernelGGL(ka::prep_labels_kernel, dim3(n), dim3(256), 0, stream, d_lats, d_meta);
     if (e->profiling) KA_HIP(hipEventRecord(e->ev[1], stream));
     if (n_fast > 0) {
+        // few lattices: 4 wavefronts per lattice (per-frame latency); many: 1 wavefront per lattice (throughput)
+        const bool wg = e->mode == KA_MODE_WORKGROUP || (e->mode == KA_MODE_AUTO && n_fast <= kAutoWorkgroupMaxLattices);
         switch (max_move) {
-        case 1: launch_forward<1>(d_lats, n_fast, d_meta, stream); break;
-        case 2: launch_forward<2>(d_lats, n_fast, d_meta, stream); break;
-        case 3: launch_forward<3>(d_lats, n_fast, d_meta, stream); break;
-        default: launch_forward<4>(d_lats, n_fast, d_meta, stream); break;
+        case 1: launch_forward<1>(d_lats, n_fast, d_meta, stream, wg); break;
+        case 2: launch_forward<2>(d_lats, n_fast, d_meta, stream, wg); break;
+        case 3: launch_forward<3>(d_lats, n_fast, d_meta, stream, wg); break;
+        default: launch_forward<4>(d_lats, n_fast, d_meta, stream, wg); break;
         }
     }
     if (n > n_fast)
         hipLaunchKernelGGL(ka::forward_generic_kernel, dim3(n - n_fast), dim3(256), 0, stream, d_lats + n_fast, d_meta);
     if (e->profiling) KA_HIP(hipEventRecord(e->ev[2], stream));
+#ifndef KA_DEBUG_NOBT
     if (n_fast > 0)
         hipLaunchKernelGGL(ka::backtrace_w16_kernel, dim3(n_fast), dim3(64), 0, stream, d_lats, d_meta);
+#endif
     if (n > n_fast)
         hipLaunchKernelGGL(ka::backtrace_generic_kernel, dim3(n - n_fast), dim3(64), 0, stream, d_lats + n_fast, d_meta);
     if (e->profiling) KA_HIP(hipEventRecord(e->ev[3], stream));
+#ifndef KA_DEBUG_DUMP
     {
         int64_t t_max = 1;
         for (int32_t i = 0; i < n; ++i) t_max = std::max<int64_t>(t_max, sh[i].T);
@@ -346,6 +371,7 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
             hipLaunchKernelGGL(ka::gather_outputs_kernel, dim3(gx, gy), dim3(256), 0, stream, d_lats + y0, d_meta);
         }
     }
+#endif
     if (e->profiling) KA_HIP(hipEventRecord(e->ev[4], stream));
     KA_HIP(hipGetLastError());
 

@@ -477,6 +477,18 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
         }
     }
 
+    // Drain the row prefetches that are still in flight (the last D frames prefetch clamped rows that are
+    // never consumed).  Their destination registers are dead to the compiler after the loop: without this
+    // wait it reuses them for the reduction below and a late-landing load overwrites live values.
+#pragma unroll
+    for (int i = 0; i < D; ++i) row_wait<0>(rows[i]);
+
+#ifdef KA_DEBUG_DUMP
+    for (int k = 0; k < 16; ++k) {
+        ((gf32_t)d.sc_out)[lane * 16 + k] = sc[k];
+        ((gi32_t)d.lab_out)[lane * 16 + k] = (blk * 16 + k) | (((pres2 >> (2 * k)) & 1u) << 30);
+    }
+#endif
     // terminal state: the HIGHEST live position of frame T-1 (align.py:99-101)
     int best = -1;
     if (pres2) best = blk * 16 + ((31 - __clz((int)pres2)) >> 1);
@@ -513,6 +525,343 @@ __global__ __launch_bounds__(64, KA_FWD_MIN_WAVES) void forward_w16_kernel(const
     const int zl = __builtin_amdgcn_readfirstlane(meta_of(meta, d.idx)[2] & 1);
     if ((zl != 0) != ZL) return;
     forward_w16<M, ZL>(d, meta);
+}
+
+// ---------------------------------------------------------------------------------------
+// forward DP, latency form ("wg4"): one 256-thread workgroup (4 wavefronts) per lattice
+//
+// Same recurrence, same 1024-slot ring, same back-pointer layout as w16, but each lane owns 4
+// consecutive positions instead of 16, so a frame is ~1/4 of the instructions per wavefront.
+// The three neighbours of a wave's lane 0 live in the previous wave's lane 63: each wave drops
+// them into a double-buffered LDS slot at the end of a frame and the workgroup meets at ONE
+// s_barrier per frame.  Used when there are too few lattices to fill the chip with one
+// wavefront each (single files, a book's few dozen chapters): per-frame latency is what counts there.
+// ---------------------------------------------------------------------------------------
+#ifndef KA_WG_ROW_WAIT
+#define KA_WG_ROW_WAIT (2 * (kRowDepth - 2))
+#endif
+struct BandMasks4 {
+    uint64_t m0, m1, m2, m3;
+    template <int K>
+    __device__ __forceinline__ uint64_t &at()
+    {
+        if constexpr (K == 0) return m0;
+        else if constexpr (K == 1) return m1;
+        else if constexpr (K == 2) return m2;
+        else return m3;
+    }
+};
+// lanes [x, y) of a 64-bit mask, 0 <= x, y <= 64
+__device__ __forceinline__ uint64_t lane_range(uint32_t x, uint32_t y)
+{
+    if (y <= x) return 0ull;
+    const uint32_t n = y - x;
+    return (n >= 64u ? ~0ull : ((1ull << n) - 1ull)) << x;
+}
+// mask of wave `wv` for cell index K: sub-slot u = 64*wv + lane holds position 4u+K (mod 1024)
+template <int K>
+__device__ __forceinline__ uint64_t band_mask4(uint32_t lo, uint32_t hi, uint32_t wv)
+{
+    const uint32_t first = (lo + 3u - (uint32_t)K) >> 2;   // ceil((lo-K)/4)
+    const uint32_t last = (hi + 3u - (uint32_t)K) >> 2;
+    const uint32_t cnt = last - first;                     // <= 253
+    const uint32_t a = (first - 64u * wv) & 255u;          // first in-band sub-slot relative to this wave's lane 0
+    const uint32_t e1 = a + cnt;                           // one past the last, before wrapping at 256
+    uint64_t m = lane_range(a < 64u ? a : 64u, e1 < 64u ? e1 : 64u);
+    if (e1 > 256u) {
+        const uint32_t w = e1 - 256u;
+        m |= lane_range(0u, w < 64u ? w : 64u);
+    }
+    return m;
+}
+__device__ __forceinline__ void band_rebuild4(BandMasks4 &mk, uint32_t lo, uint32_t hi, uint32_t wv)
+{
+    mk.m0 = band_mask4<0>(lo, hi, wv);
+    mk.m1 = band_mask4<1>(lo, hi, wv);
+    mk.m2 = band_mask4<2>(lo, hi, wv);
+    mk.m3 = band_mask4<3>(lo, hi, wv);
+}
+__device__ __forceinline__ void band_toggle4(BandMasks4 &mk, uint32_t p, uint32_t wv)
+{
+    const uint32_t u = (p >> 2) & 255u;
+    if ((u >> 6) != wv) return;
+    const uint64_t bit = 1ull << (u & 63u);
+    switch (p & 3u) {
+    case 0: mk.m0 ^= bit; break;
+    case 1: mk.m1 ^= bit; break;
+    case 2: mk.m2 ^= bit; break;
+    default: mk.m3 ^= bit; break;
+    }
+}
+__device__ __forceinline__ uint32_t pair_mask4(int n)
+{
+    n = n < 0 ? 0 : (n > 4 ? 4 : n);
+    return ((1u << (2 * n)) - 1u) & 0x55u;
+}
+template <int M, bool ZL, int K>
+__device__ __forceinline__ void frame_cells4(float (&sc)[4], float h1, float h2, float h3, const float (&ec)[2],
+                                             const float (&vz)[2], float e0, BandMasks4 &mk, float NINF, uint32_t &word)
+{
+    const float a0 = sc[K];
+    const float a1 = K >= 1 ? sc[K >= 1 ? K - 1 : 0] : h1;
+    const float a2 = K >= 2 ? sc[K >= 2 ? K - 2 : 0] : (K == 1 ? h1 : h2);
+    const float a3 = K >= 3 ? sc[K >= 3 ? K - 3 : 0] : (K == 2 ? h1 : (K == 1 ? h2 : h3));
+    float m;
+    if constexpr (K & 1)
+        cell_label<M, ZL>(a0, a1, a2, a3, ec[K >> 1], vz[K >> 1], m, word);
+    else
+        cell_blank<M>(a0, a1, a3, e0, m, word);
+    sc[K] = select_by_mask(NINF, m, mk.at<K>());
+    if constexpr (K > 0) frame_cells4<M, ZL, K - 1>(sc, h1, h2, h3, ec, vz, e0, mk, NINF, word);
+}
+
+template <int M, bool ZL>
+__device__ __forceinline__ void forward_wg4(const Lattice &d, int32_t *meta)
+{
+    constexpr int D = kRowDepth;
+    // [frame parity][wave][h1, h2, h3, re-labelled flag] of each wave's lane 63
+    __shared__ float s_halo[2][4][4];
+    __shared__ int s_best[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
+    const int quad = tid & 3;                 // which quarter of its 16-position block this thread owns
+    const int sub = tid >> 2;                 // block lane (0..63), like a w16 lane
+    const uint32_t T = (uint32_t)__builtin_amdgcn_readfirstlane(d.T);
+    const uint32_t L = (uint32_t)__builtin_amdgcn_readfirstlane(d.L);
+    const uint32_t B = (uint32_t)__builtin_amdgcn_readfirstlane(d.beam);
+    const uint32_t halfB = B >> 1;
+    const uint32_t dq = L / T, dr = L % T;
+    const float NINF = ninf();
+
+    float sc[4] = {NINF, NINF, NINF, NINF};
+    if (tid == 0) sc[0] = 0.0f;             // virtual state before frame 0 (align.py:57-58)
+    uint32_t pres2 = tid == 0 ? 1u : 0u;    // bit 2k: cell k holds a live state
+    bool pend_reset = false, reset_lane = false;
+
+    int blk = sub;
+    uint32_t blo = 0;
+    gci32_t labx = (gci32_t)d.labx;
+    int la[2];
+    float vz[2];
+    la[0] = labx[(size_t)blk * 8 + 2 * quad];
+    la[1] = labx[(size_t)blk * 8 + 2 * quad + 1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) vz[i] = (ZL && la[i] == 0) ? NINF : __builtin_inff();
+
+    uint32_t q = 0, rem = 0;
+    uint32_t lo = 0, hi = B < L ? B : L;
+    BandMasks4 mk;
+    band_rebuild4(mk, lo, hi, wv);
+    uint32_t band2 = pair_mask4((int)hi - (blk * 16 + 4 * quad)) & ~pair_mask4((int)lo - (blk * 16 + 4 * quad));
+
+    const uint32_t lane_off = (lane < d.V ? (uint32_t)lane : 0u) * 4u;
+    const char *lp = reinterpret_cast<const char *>(d.lp);
+    const size_t ld = (size_t)d.ld * 4;
+    float rows[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const uint32_t tt = (uint32_t)i < T ? (uint32_t)i : T - 1;
+        rows[i] = row_load(lane_off, lp + (size_t)tt * ld);
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) row_wait<0>(rows[i]);
+    float e[2][2], e0[2];
+    e[0][0] = bperm(la[0], rows[0]);
+    e[0][1] = bperm(la[1], rows[0]);
+    e0[0] = first_lane(rows[0]);
+
+    const uint32_t *bp = reinterpret_cast<const uint32_t *>(d.bp);
+    const uint32_t store_off = (uint32_t)sub * 4u;       // dword (tid>>2) of the frame's 64-dword row
+    const int prev_wave = (int)((wv + 3u) & 3u);
+
+    if (lane == 63) {
+        s_halo[0][wv][0] = NINF; s_halo[0][wv][1] = NINF; s_halo[0][wv][2] = NINF; s_halo[0][wv][3] = 0.0f;
+    }
+    __syncthreads();
+
+    for (uint32_t tb = 0; tb < T; tb += D) {
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) {
+            const uint32_t t = tb + dd;
+            if (t < T) {
+                const int par = (int)(t & 1u);
+                // A. band of frame t+1; re-label the threads whose block has been passed by lo
+                uint32_t nq = q + dq, nrem = rem + dr;
+                if (nrem >= T) { nrem -= T; ++nq; }
+                const int32_t dlo = (int32_t)nq - (int32_t)halfB;
+                uint32_t nlo = (uint32_t)(dlo > 0 ? dlo : 0);
+                uint32_t nhi = (L - nlo < B) ? L : nlo + B;
+                if (t + 1 == T) { nlo = lo; nhi = hi; }
+                bool relabeled = false, relabel_lane = false;
+                if ((nlo >> 4) != blo) {
+                    blo = nlo >> 4;
+                    const int nb = (int)blo + ((sub - (int)blo) & 63);
+                    if (nb != blk) {
+                        blk = nb;
+                        la[0] = labx[(size_t)blk * 8 + 2 * quad];
+                        la[1] = labx[(size_t)blk * 8 + 2 * quad + 1];
+                        relabel_lane = true;
+                        asm volatile("" : "+v"(la[0]), "+v"(la[1]));
+                    }
+                    relabeled = true;
+                }
+                // B. emissions of frame t+1
+                {
+                    row_wait<KA_WG_ROW_WAIT>(rows[(dd + 1) % D]);
+                    const float rn = rows[(dd + 1) % D];
+                    e[(dd + 1) & 1][0] = bperm(la[0], rn);
+                    e[(dd + 1) & 1][1] = bperm(la[1], rn);
+                    e0[(dd + 1) & 1] = first_lane(rn);
+                }
+                // C. frame t.  Left neighbours: previous lane (DPP), or for lane 0 the previous wave's lane 63 (LDS)
+                float h1 = wave_ror1(sc[3]), h2 = wave_ror1(sc[2]), h3 = wave_ror1(sc[1]);
+                {
+                    const float l1 = s_halo[par][prev_wave][0], l2 = s_halo[par][prev_wave][1], l3 = s_halo[par][prev_wave][2];
+                    h1 = lane == 0 ? l1 : h1;
+                    h2 = lane == 0 ? l2 : h2;
+                    h3 = lane == 0 ? l3 : h3;
+                }
+                if (__builtin_expect(pend_reset, 0)) {
+                    asm volatile("" ::: "memory");
+                    bool left_reset = __builtin_amdgcn_update_dpp(0, (int)reset_lane, 0x13C, 0xF, 0xF, false) != 0;
+                    if (lane == 0) left_reset = s_halo[par][prev_wave][3] != 0.0f;
+                    const bool kill = reset_lane && left_reset;
+                    h1 = kill ? NINF : h1;
+                    h2 = kill ? NINF : h2;
+                    h3 = kill ? NINF : h3;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sc[k] = reset_lane ? NINF : sc[k];
+                    pres2 = reset_lane ? 0u : pres2;
+                }
+                uint32_t word = 0;
+                frame_cells4<M, ZL, 3>(sc, h1, h2, h3, e[dd & 1], vz, e0[dd & 1], mk, NINF, word);
+                // hand this wave's top three scores (and whether lane 63 will be re-labelled) to the next wave
+                if (lane == 63) {
+                    s_halo[par ^ 1][wv][0] = sc[3];
+                    s_halo[par ^ 1][wv][1] = sc[2];
+                    s_halo[par ^ 1][wv][2] = sc[1];
+                    s_halo[par ^ 1][wv][3] = relabel_lane ? 1.0f : 0.0f;
+                }
+                {
+                    const uint32_t hib = (word >> 1) & 0x55u, lob = word & 0x55u;
+                    const uint32_t stay = hib & (lob | 0x11u);
+                    pres2 = (pres2 | (~stay & 0x55u)) & band2;
+                }
+                // 4 threads x 8 bits -> the block's dword (same layout as w16), stored by the block's first thread
+                uint32_t x = word << (8 * quad);
+                x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+                x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+                if (quad == 0)
+                    asm volatile("global_store_dword %0, %1, %2" : : "v"(store_off), "v"(x), "s"(bp + (size_t)t * 64) : "memory");
+                {
+                    const uint32_t tt = t + D < T ? t + D : T - 1;
+                    rows[dd] = row_load(lane_off, lp + (size_t)tt * ld);
+                }
+                // D. lane masks of frame t+1
+                if (nlo != lo || nhi != hi) {
+                    if ((nhi - hi) + (nlo - lo) <= 6u) {
+                        for (uint32_t p = hi; p < nhi; ++p) band_toggle4(mk, p, wv);
+                        for (uint32_t p = lo; p < nlo; ++p) band_toggle4(mk, p, wv);
+                    } else {
+                        band_rebuild4(mk, nlo, nhi, wv);
+                    }
+                    band2 = pair_mask4((int)nhi - (blk * 16 + 4 * quad)) & ~pair_mask4((int)nlo - (blk * 16 + 4 * quad));
+                    lo = nlo;
+                    hi = nhi;
+                    if (ZL && relabeled) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) vz[i] = la[i] == 0 ? NINF : __builtin_inff();
+                    }
+                }
+                q = nq;
+                rem = nrem;
+                pend_reset = relabeled;
+                reset_lane = relabel_lane;
+                // one rendezvous per frame: LDS writes of this frame are visible before anyone reads them in the next
+#ifdef KA_WG_SYNCTHREADS
+                __syncthreads();
+#else
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#endif
+            }
+        }
+    }
+
+    // Drain the row prefetches that are still in flight (the last D frames prefetch clamped rows that are
+    // never consumed).  Their destination registers are dead to the compiler after the loop: without this
+    // wait it reuses them for the reduction below and a late-landing load overwrites live values.
+#pragma unroll
+    for (int i = 0; i < D; ++i) row_wait<0>(rows[i]);
+
+    // terminal state: the HIGHEST live position of frame T-1 (align.py:99-101)
+    int best = -1;
+    if (pres2) best = blk * 16 + 4 * quad + ((31 - __clz((int)pres2)) >> 1);
+#ifdef KA_WG_ATOMIC_REDUCE
+    __shared__ int s_max;
+    if (tid == 0) s_max = -1;
+    __syncthreads();
+    if (best >= 0) atomicMax(&s_max, best);
+    __syncthreads();
+    best = s_max;
+#else
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const int o = __shfl_xor(best, off);
+        best = o > best ? o : best;
+    }
+#endif
+#ifdef KA_WG_EXTRA_SYNC
+    __syncthreads();
+#endif
+#ifdef KA_DEBUG_DUMP
+    // debug build only: final score column / position / live flags of every slot into the output arrays
+    for (int k = 0; k < 4; ++k) {
+        ((gf32_t)d.sc_out)[tid * 4 + k] = sc[k];
+        ((gi32_t)d.lab_out)[tid * 4 + k] = (blk * 16 + 4 * quad + k) | (((pres2 >> (2 * k)) & 1u) << 30);
+    }
+#endif
+#ifdef KA_DEBUG_STAMP
+    const int my_best = best;
+    const unsigned long long t_w = __builtin_amdgcn_s_memtime();
+#endif
+    if (lane == 0) s_best[wv] = best;
+    __syncthreads();
+#ifdef KA_DEBUG_STAMP
+    {
+        const unsigned long long t_r = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {   // per wave: [my best, s_best[0..3] as read, t_write, t_read] into lab_out (debug build only)
+            gi32_t o = (gi32_t)d.lab_out + wv * 16;
+            o[0] = my_best; o[1] = s_best[0]; o[2] = s_best[1]; o[3] = s_best[2]; o[4] = s_best[3];
+            o[5] = (int)(t_w & 0x7fffffff); o[6] = (int)(t_r & 0x7fffffff); o[7] = (int)T;
+        }
+    }
+#endif
+    best = s_best[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) best = s_best[w] > best ? s_best[w] : best;
+    int32_t *m = meta_of(meta, d.idx);
+    if (best < 0) {
+        if (tid == 0) {
+            m[1] = -1;
+            atomicMin(&m[0], kStatusEmptyBeam);
+        }
+    } else if ((best >> 2) == blk * 4 + quad) {
+        float v = sc[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) v = (best & 3) == k ? sc[k] : v;
+        m[1] = best;
+        m[3] = __builtin_bit_cast(int32_t, v);
+    }
+}
+
+template <int M, bool ZL>
+__global__ __launch_bounds__(256) void forward_wg4_kernel(const Lattice *__restrict__ lats, int32_t *meta)
+{
+    const Lattice &d = lats[blockIdx.x];
+    const int zl = __builtin_amdgcn_readfirstlane(meta_of(meta, d.idx)[2] & 1);
+    if ((zl != 0) != ZL) return;
+    forward_wg4<M, ZL>(d, meta);
 }
 
 // ---------------------------------------------------------------------------------------

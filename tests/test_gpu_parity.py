@@ -13,13 +13,18 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ka():
+@pytest.fixture(scope="module", params=["wave", "workgroup"])
+def ka(request):
+    """Every test runs with both forms of the forward kernel: one wavefront per lattice (throughput)
+    and four wavefronts per lattice (latency).  Results must be identical."""
     import torch
     assert torch.cuda.is_available()
     import kokoro_align_amd as ka
+    from kokoro_align_amd import _lib
     assert os.path.exists(ka.library_path()), "HIP library not built"
-    return ka
+    _lib.default_engine(torch.cuda.current_device()).set_mode(request.param)
+    yield ka
+    _lib.default_engine(torch.cuda.current_device()).set_mode("auto")
 
 
 def _same(got, want):
@@ -255,3 +260,28 @@ def test_repeatability_tiny_lattices(ka):
         for c in cases[rep % 3::3]:
             p, l, s = ka.ctc_best_path(c["lp"], c["labels"], beam_size=c["beam"], max_move=c["max_move"], verbose=False)
             assert np.array_equal(p, c["path"]), (rep, c["idx"])
+
+
+def test_many_lattices_under_memory_pressure(ka):
+    """Regression: with hundreds of lattices in flight the log-prob prefetches land late; a prefetch that was
+    still in flight after the last frame used to overwrite registers of the end-position reduction
+    (about 2 % of the lattices ended one to a few positions low).  Every end must be the trailing blank
+    and sampled lattices must equal the oracle."""
+    import torch
+    B, T, V, S = 768, 6000, 64, 600
+    lib = ka.load_library()
+    lps = torch.empty((B, T, V), dtype=torch.float32, device="cuda")
+    labs = torch.empty((B, S), dtype=torch.int32, device="cuda")
+    assert lib.ka_hash_logprobs_batch_f32(lps.data_ptr(), B, T, V, V, T * V, 7000, None) == 0
+    assert lib.ka_hash_labels_batch_i32(labs.data_ptr(), B, S, V, S, 7000, None) == 0
+    torch.cuda.synchronize()
+    from kokoro_align_amd.align import DeviceBatch
+    batch = DeviceBatch([lps[i] for i in range(B)], [labs[i] for i in range(B)])
+    for rep in range(3):
+        batch.run()
+        ends = torch.stack([p[-1] for p in batch.path]).cpu().numpy()
+        assert (ends == 2 * S).all(), np.nonzero(ends != 2 * S)[0][:10]
+    for i in (0, 1, B // 2, B - 1):
+        want = O.ctc_best_path_c(O.hash_logprobs(T, V, 7000 + i), O.hash_labels(S, V, 7000 + i))
+        assert np.array_equal(batch.path[i].cpu().numpy(), want[0]), i
+        assert np.array_equal(batch.best_labels[i].cpu().numpy(), want[1]), i

@@ -1,0 +1,32 @@
+"""Batch of cfg2 lattices in a chosen kernel form; compare a sample of them with the CPU oracle."""
+import sys, os
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+import numpy as np, torch
+import kokoro_align_amd as ka
+from kokoro_align_amd.align import DeviceBatch
+from oracle import oracle as O
+
+B = int(sys.argv[1]); mode = sys.argv[2]; T = int(sys.argv[3]) if len(sys.argv) > 3 else 50000
+V, S = 64, T // 10
+lib = ka.load_library()
+lps = torch.empty((B, T, V), dtype=torch.float32, device="cuda")
+labs = torch.empty((B, S), dtype=torch.int32, device="cuda")
+assert lib.ka_hash_logprobs_batch_f32(lps.data_ptr(), B, T, V, V, T * V, 0, None) == 0
+assert lib.ka_hash_labels_batch_i32(labs.data_ptr(), B, S, V, S, 0, None) == 0
+torch.cuda.synchronize()
+batch = DeviceBatch([lps[i] for i in range(B)], [labs[i] for i in range(B)], 1000, 4)
+batch.engine.set_mode(mode)
+for rep in range(3):
+    batch.run()
+    ends = np.array([int(p[-1]) for p in batch.path])
+    nbad_end = int((ends != 2 * S).sum())
+    bad = []
+    wrong = np.nonzero(ends != 2 * S)[0][:4].tolist()
+    for i in sorted(set([0, 1, B - 1] + wrong)):
+        want = O.ctc_best_path_c(O.hash_logprobs(T, V, i), O.hash_labels(S, V, i), 1000, 4)
+        got = batch.path[i].cpu().numpy()
+        if not np.array_equal(got, want[0]):
+            j = int(np.argmax(got != want[0]))
+            bad.append((i, j, int((got != want[0]).sum()), got[j:j+4].tolist(), want[0][j:j+4].tolist(), int(got[-1])))
+    print(f"rep {rep} mode={mode} B={B} T={T}: ends wrong: {nbad_end} (idx {np.nonzero(ends != 2 * S)[0][:8].tolist()}); sample mismatches: {bad}")
