@@ -285,3 +285,84 @@ def test_many_lattices_under_memory_pressure(ka):
         want = O.ctc_best_path_c(O.hash_logprobs(T, V, 7000 + i), O.hash_labels(S, V, 7000 + i))
         assert np.array_equal(batch.path[i].cpu().numpy(), want[0]), i
         assert np.array_equal(batch.best_labels[i].cpu().numpy(), want[1]), i
+
+
+def test_cfg5_long_form_band(ka):
+    """BASELINE configs[4] with the default band: T=500000 x V=64, S=50000 (L=100001); 128 MB of back-pointers."""
+    import torch
+    T, V, S = 500000, 64, 50000
+    lib = ka.load_library()
+    lp = torch.empty((T, V), dtype=torch.float32, device="cuda")
+    lab = torch.empty(S, dtype=torch.int32, device="cuda")
+    assert lib.ka_hash_logprobs_f32(lp.data_ptr(), T, V, V, 55, None) == 0
+    assert lib.ka_hash_labels_i32(lab.data_ptr(), S, V, 55, None) == 0
+    torch.cuda.synchronize()
+    (p, l, s), = ka.ctc_best_path_device([lp], [lab])
+    want = O.ctc_best_path_c(O.hash_logprobs(T, V, 55), O.hash_labels(S, V, 55))
+    assert np.array_equal(p.cpu().numpy(), want[0])
+    assert np.array_equal(l.cpu().numpy(), want[1])
+    assert np.array_equal(s.cpu().numpy().view(np.int32), want[2].view(np.int32))
+
+
+def test_host_strided_rows_and_engine_reuse(ka):
+    """Host buffers whose row stride exceeds V go through the C ABI directly; one engine serves calls of
+    very different sizes back to back (workspace growth) and an explicit reserve."""
+    import ctypes
+    from kokoro_align_amd import _lib
+    rng = np.random.default_rng(21)
+    eng = _lib.Engine(0)
+    eng.set_mode("auto")
+    try:
+        for T, V, ld, S in [(300, 39, 48, 120), (9000, 39, 39, 3000), (50, 5, 64, 10), (4000, 64, 80, 1500)]:
+            buf = np.full((T, ld), np.nan, np.float32)          # NaN padding must never be read
+            lp = rng.standard_normal((T, V)).astype(np.float32)
+            buf[:, :V] = lp
+            labels = rng.integers(1, V, size=S).astype(np.int32)
+            want = O.ctc_best_path_c(lp, labels, 1000, 4, return_total=True)
+            path = np.empty(T, np.int32); lout = np.empty(T, np.int32); sout = np.empty(T, np.float32)
+            total = ctypes.c_float(0)
+            rc = eng.lib.ka_ctc_best_path_f32(eng.handle, buf.ctypes.data, T, V, ld, labels.ctypes.data, S, 1000, 4,
+                                              path.ctypes.data, lout.ctypes.data, sout.ctypes.data,
+                                              ctypes.addressof(total), _lib.KA_MEM_HOST, None)
+            assert rc == 0, _lib.last_error()
+            assert np.array_equal(path, want[0]) and np.array_equal(lout, want[1])
+            assert np.array_equal(sout.view(np.int32), want[2].view(np.int32))
+            assert np.float32(total.value).view(np.int32) == np.float32(want[3]).view(np.int32)
+        eng.reserve(64 << 20)
+        n = (ctypes.c_int64 * 1)(1000); s = (ctypes.c_int64 * 1)(100)
+        assert eng.lib.ka_workspace_bytes(1, n, s, 39, 1000, 4) >= 1000 * 256
+        assert eng.lib.ka_workspace_bytes(1, n, s, 39, 1000, 300) == 0        # max_move out of range -> 0
+    finally:
+        eng.close()
+
+
+def test_non_default_stream_and_two_engines(ka):
+    """Device buffers on a side stream; a second engine in another host thread at the same time."""
+    import threading
+    import torch
+    from kokoro_align_amd import _lib
+    rng = np.random.default_rng(22)
+    lp, labels = _rand_case(rng, 5000, 39, 1800)
+    want = O.ctc_best_path_c(lp, labels, 1000, 4)
+    results = {}
+
+    def worker(name):
+        eng = _lib.Engine(0)
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                d = torch.from_numpy(lp).cuda()
+                from kokoro_align_amd.align import DeviceBatch
+                b = DeviceBatch([d] * 3, [torch.from_numpy(labels).cuda()] * 3)
+                b.engine = eng
+                for _ in range(3):
+                    b.run()
+                results[name] = [x.cpu().numpy() for x in b.path]
+        finally:
+            eng.close()
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for name in (0, 1):
+        assert all(np.array_equal(p, want[0]) for p in results[name]), name
