@@ -93,15 +93,22 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal knobs (never set by the driver): several ranks on ONE GPU over gloo, to exercise the
+    # multi-rank control flow on a single-GPU box
+    rehearsal = os.environ.get("KA_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1 or os.environ.get("KA_FORCE_DIST") == "1":   # KA_FORCE_DIST: exercise the RCCL path with one rank
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
         # start-up collective of the pipeline: broadcast of the acoustic-model weights (2.3 MB)
         from kokoro_align_amd.sharding import broadcast_model_weights
-        broadcast_model_weights(dev)
+        broadcast_model_weights(torch.device("cpu") if rehearsal else dev)
 
     lib = ka.load_library()
     B = args.lattices
@@ -131,7 +138,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier() if rehearsal else dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -146,7 +153,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -214,7 +221,7 @@ def main():
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier() if rehearsal else dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 
