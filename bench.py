@@ -185,6 +185,8 @@ def main():
         fwd_b, job_b, wbar = algorithmic_bytes_per_frame()
         fwd_s = float(np.mean(fwd_ms)) * 1e-3
         achieved = B * T * fwd_b / fwd_s / 1e9
+        # HBM bytes of one forward launch cannot be counted from inside this process: they come from the
+        # committed rocprofv3 PMC run (tools/prof.sh -> tools/summarize_profile.py) at the same batch size
         traffic = None
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tf):
@@ -205,6 +207,7 @@ def main():
                        "lattices_per_gpu": B, "frames_per_step": frames_per_step, "parallelism": f"lattice-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same batch size)" if traffic else None,
                          "kernel": "forward_w16_kernel<4,false>", "kernel_ms": fwd_s * 1e3,
                          "algorithmic_bytes_per_frame": fwd_b, "mean_band_width": wbar},
             "kernels_ms": {"prep": float(np.mean(prep_ms)), "forward": float(np.mean(fwd_ms)),

@@ -354,14 +354,11 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
     if (n > n_fast)
         hipLaunchKernelGGL(ka::forward_generic_kernel, dim3(n - n_fast), dim3(256), 0, stream, d_lats + n_fast, d_meta);
     if (e->profiling) KA_HIP(hipEventRecord(e->ev[2], stream));
-#ifndef KA_DEBUG_NOBT
     if (n_fast > 0)
         hipLaunchKernelGGL(ka::backtrace_w16_kernel, dim3(n_fast), dim3(64), 0, stream, d_lats, d_meta);
-#endif
     if (n > n_fast)
         hipLaunchKernelGGL(ka::backtrace_generic_kernel, dim3(n - n_fast), dim3(64), 0, stream, d_lats + n_fast, d_meta);
     if (e->profiling) KA_HIP(hipEventRecord(e->ev[3], stream));
-#ifndef KA_DEBUG_DUMP
     {
         int64_t t_max = 1;
         for (int32_t i = 0; i < n; ++i) t_max = std::max<int64_t>(t_max, sh[i].T);
@@ -371,7 +368,6 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
             hipLaunchKernelGGL(ka::gather_outputs_kernel, dim3(gx, gy), dim3(256), 0, stream, d_lats + y0, d_meta);
         }
     }
-#endif
     if (e->profiling) KA_HIP(hipEventRecord(e->ev[4], stream));
     KA_HIP(hipGetLastError());
 

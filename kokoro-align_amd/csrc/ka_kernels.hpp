@@ -483,12 +483,6 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
 #pragma unroll
     for (int i = 0; i < D; ++i) row_wait<0>(rows[i]);
 
-#ifdef KA_DEBUG_DUMP
-    for (int k = 0; k < 16; ++k) {
-        ((gf32_t)d.sc_out)[lane * 16 + k] = sc[k];
-        ((gi32_t)d.lab_out)[lane * 16 + k] = (blk * 16 + k) | (((pres2 >> (2 * k)) & 1u) << 30);
-    }
-#endif
     // terminal state: the HIGHEST live position of frame T-1 (align.py:99-101)
     int best = -1;
     if (pres2) best = blk * 16 + ((31 - __clz((int)pres2)) >> 1);
@@ -537,9 +531,6 @@ __global__ __launch_bounds__(64, KA_FWD_MIN_WAVES) void forward_w16_kernel(const
 // s_barrier per frame.  Used when there are too few lattices to fill the chip with one
 // wavefront each (single files, a book's few dozen chapters): per-frame latency is what counts there.
 // ---------------------------------------------------------------------------------------
-#ifndef KA_WG_ROW_WAIT
-#define KA_WG_ROW_WAIT (2 * (kRowDepth - 2))
-#endif
 struct BandMasks4 {
     uint64_t m0, m1, m2, m3;
     template <int K>
@@ -707,7 +698,7 @@ __device__ __forceinline__ void forward_wg4(const Lattice &d, int32_t *meta)
                 }
                 // B. emissions of frame t+1
                 {
-                    row_wait<KA_WG_ROW_WAIT>(rows[(dd + 1) % D]);
+                    row_wait<2 * (D - 2)>(rows[(dd + 1) % D]);
                     const float rn = rows[(dd + 1) % D];
                     e[(dd + 1) & 1][0] = bperm(la[0], rn);
                     e[(dd + 1) & 1][1] = bperm(la[1], rn);
@@ -778,12 +769,8 @@ __device__ __forceinline__ void forward_wg4(const Lattice &d, int32_t *meta)
                 pend_reset = relabeled;
                 reset_lane = relabel_lane;
                 // one rendezvous per frame: LDS writes of this frame are visible before anyone reads them in the next
-#ifdef KA_WG_SYNCTHREADS
-                __syncthreads();
-#else
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-#endif
             }
         }
     }
@@ -797,46 +784,13 @@ __device__ __forceinline__ void forward_wg4(const Lattice &d, int32_t *meta)
     // terminal state: the HIGHEST live position of frame T-1 (align.py:99-101)
     int best = -1;
     if (pres2) best = blk * 16 + 4 * quad + ((31 - __clz((int)pres2)) >> 1);
-#ifdef KA_WG_ATOMIC_REDUCE
-    __shared__ int s_max;
-    if (tid == 0) s_max = -1;
-    __syncthreads();
-    if (best >= 0) atomicMax(&s_max, best);
-    __syncthreads();
-    best = s_max;
-#else
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         const int o = __shfl_xor(best, off);
         best = o > best ? o : best;
     }
-#endif
-#ifdef KA_WG_EXTRA_SYNC
-    __syncthreads();
-#endif
-#ifdef KA_DEBUG_DUMP
-    // debug build only: final score column / position / live flags of every slot into the output arrays
-    for (int k = 0; k < 4; ++k) {
-        ((gf32_t)d.sc_out)[tid * 4 + k] = sc[k];
-        ((gi32_t)d.lab_out)[tid * 4 + k] = (blk * 16 + 4 * quad + k) | (((pres2 >> (2 * k)) & 1u) << 30);
-    }
-#endif
-#ifdef KA_DEBUG_STAMP
-    const int my_best = best;
-    const unsigned long long t_w = __builtin_amdgcn_s_memtime();
-#endif
     if (lane == 0) s_best[wv] = best;
     __syncthreads();
-#ifdef KA_DEBUG_STAMP
-    {
-        const unsigned long long t_r = __builtin_amdgcn_s_memtime();
-        if (lane == 0) {   // per wave: [my best, s_best[0..3] as read, t_write, t_read] into lab_out (debug build only)
-            gi32_t o = (gi32_t)d.lab_out + wv * 16;
-            o[0] = my_best; o[1] = s_best[0]; o[2] = s_best[1]; o[3] = s_best[2]; o[4] = s_best[3];
-            o[5] = (int)(t_w & 0x7fffffff); o[6] = (int)(t_r & 0x7fffffff); o[7] = (int)T;
-        }
-    }
-#endif
     best = s_best[0];
 #pragma unroll
     for (int w = 1; w < 4; ++w) best = s_best[w] > best ? s_best[w] : best;
