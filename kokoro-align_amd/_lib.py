@@ -4,6 +4,7 @@ The shared library is built in-tree by ``build_library()`` (kokoro-align_amd/csr
 hipcc --offload-arch=gfx950) and loaded from the package directory.  A missing library is an
 error: there is no fallback implementation.
 """
+import atexit
 import ctypes
 import os
 import subprocess
@@ -162,6 +163,16 @@ class Engine:
 
 
 _engines = {}
+
+
+def _close_engines():
+    # release device memory while the HIP runtime is still alive (not from __del__ at interpreter teardown)
+    for e in list(_engines.values()):
+        e.close()
+    _engines.clear()
+
+
+atexit.register(_close_engines)
 
 
 def default_engine(device=0):
