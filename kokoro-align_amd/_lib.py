@@ -7,6 +7,7 @@ error: there is no fallback implementation.
 import atexit
 import ctypes
 import os
+import shutil
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
@@ -53,6 +54,8 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(_SO) and not os.environ.get("KA_LIBRARY") and shutil.which("hipcc", path=os.environ.get("PATH", "") + ":/opt/rocm/bin"):
+        build_library()          # same HIP sources, built in-tree; never a different code path
     if not os.path.exists(_SO):
         raise KAError(
             f"{_SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
