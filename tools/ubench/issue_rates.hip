@@ -100,6 +100,50 @@ OP8(122, T2("v_add_f32_e64"))
 OP8(123, T3("v_max3_f32", ", %8"))
 OP8(124, "v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8\n")
 
+OP8(130, T2("v_or_b32"))
+// exec-masked bit set: s_mov exec, mask ; v_or_b32 ; ... ; restore
+template <> __global__ __launch_bounds__(64) void kk<131>(float *out, int iters, float seed) {
+    uint32_t w0 = threadIdx.x, w1 = 3;
+    uint64_t m0 = 0x0123456789abcdefull * (uint64_t)(iters | 1), m1 = ~m0;
+    for (int i = 0; i < iters; ++i) {
+        asm volatile(REP8(
+            "s_mov_b64 exec, %2\n v_or_b32 %0, 2, %0\n s_mov_b64 exec, %3\n v_or_b32 %0, 1, %0\n s_mov_b64 exec, -1\n v_add_u32 %0, %0, %0\n v_add_u32 %0, %0, %0\n"
+            "s_mov_b64 exec, %3\n v_or_b32 %1, 2, %1\n s_mov_b64 exec, %2\n v_or_b32 %1, 1, %1\n s_mov_b64 exec, -1\n v_add_u32 %1, %1, %1\n v_add_u32 %1, %1, %1\n")
+            : "+v"(w0), "+v"(w1) : "s"(m0), "s"(m1));
+    }
+    out[blockIdx.x * 64 + threadIdx.x] = (float)(w0 + w1);
+}
+// cell pattern A (current): 4 add, 2 max(max3+max), 3 cmp_eq, 3 salu, 2 addc, 1 cndmask
+template <> __global__ __launch_bounds__(64) void kk<132>(float *out, int iters, float seed) {
+    float a0 = seed + threadIdx.x, a1 = a0 * 1.1f, a2 = a0 * 1.2f, a3 = a0 * 1.3f, c0, c1, c2, c3, m, e = 0.5f; uint32_t w = 1; uint64_t mk = 0xffff0000ffff0000ull, s0, s1, s2;
+    for (int i = 0; i < iters; ++i) {
+        asm volatile(REP8(
+            "v_add_f32 %4, %0, %9\n v_add_f32 %5, %1, %9\n v_add_f32 %6, %2, %9\n v_add_f32 %7, %3, %9\n"
+            "v_max3_f32 %8, %4, %5, %6\n v_max_f32 %8, %8, %7\n"
+            "v_cmp_eq_f32 %11, %4, %8\n v_cmp_eq_f32 %12, %5, %8\n v_cmp_eq_f32 %13, %6, %8\n"
+            "s_or_b64 %11, %11, %12\n s_andn2_b64 %13, %13, %12\n s_or_b64 %13, %13, %11\n"
+            "v_addc_co_u32 %10, %12, %10, %10, %11\n v_addc_co_u32 %10, %12, %10, %10, %13\n"
+            "v_cndmask_b32 %0, %9, %8, %14\n")
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&v"(m), "+v"(e), "+v"(w), "=&s"(s0), "=&s"(s1), "=&s"(s2) : "s"(mk) : "vcc", "scc");
+    }
+    out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + e + (float)w;
+}
+// cell pattern B: same but bits set with exec-masked v_or (word pre-shifted by 2 with two fast adds)
+template <> __global__ __launch_bounds__(64) void kk<133>(float *out, int iters, float seed) {
+    float a0 = seed + threadIdx.x, a1 = a0 * 1.1f, a2 = a0 * 1.2f, a3 = a0 * 1.3f, c0, c1, c2, c3, m, e = 0.5f; uint32_t w = 1; uint64_t mk = 0xffff0000ffff0000ull, s0, s1, s2;
+    for (int i = 0; i < iters; ++i) {
+        asm volatile(REP8(
+            "v_add_f32 %4, %0, %9\n v_add_f32 %5, %1, %9\n v_add_f32 %6, %2, %9\n v_add_f32 %7, %3, %9\n"
+            "v_max3_f32 %8, %4, %5, %6\n v_max_f32 %8, %8, %7\n"
+            "v_cmp_eq_f32 %11, %4, %8\n v_cmp_eq_f32 %12, %5, %8\n v_cmp_eq_f32 %13, %6, %8\n"
+            "s_or_b64 %11, %11, %12\n s_andn2_b64 %13, %13, %12\n s_or_b64 %13, %13, %11\n"
+            "s_mov_b64 exec, %11\n v_or_b32 %10, 2, %10\n s_mov_b64 exec, %13\n v_or_b32 %10, 1, %10\n s_mov_b64 exec, -1\n"
+            "v_cndmask_b32 %0, %9, %8, %14\n")
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&v"(m), "+v"(e), "+v"(w), "=&s"(s0), "=&s"(s1), "=&s"(s2) : "s"(mk) : "vcc", "scc");
+    }
+    out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + e + (float)w;
+}
+
 template <int NAME>
 void run2(const char *name, float *d_out)
 {
@@ -111,6 +155,8 @@ void run2(const char *name, float *d_out)
         hipEventRecord(a);
         hipLaunchKernelGGL(kk<NAME>, dim3(blocks), dim3(64), 0, 0, d_out, iters, 1.0f);
         hipEventRecord(b); hipEventSynchronize(b);
+        hipError_t er = hipGetLastError();
+        if (er != hipSuccess) printf("%s: launch error %s\n", name, hipGetErrorString(er));
         float ms = 0; hipEventElapsedTime(&ms, a, b);
         printf("%-44s waves/SIMD=%d  %.3f ms  %.2f cyc per wave-instr per SIMD (@2.4GHz)\n", name, wps, ms, ms * 1e-3 * 2.4e9 / ((double)iters * 64 * wps));
     }
@@ -158,5 +204,7 @@ int main()
     run2<113>("v_xor_b32", d_out); run2<117>("v_and_b32", d_out); run2<114>("v_lshlrev_b32", d_out); run2<119>("v_ashrrev_i32", d_out);
     run2<115>("v_add3_u32", d_out); run2<116>("v_lshl_add_u32", d_out); run2<118>("v_mad_u32_u24", d_out); run2<120>("v_bitop3_b32", d_out);
     run2<124>("v_mov_b32", d_out);
+    run2<130>("v_or_b32", d_out); run2<131>("exec-masked v_or pairs (7 instr/unit, x64 => per unit)", d_out);
+    run2<132>("cell A: addc packing (15 instr per cell, reported per 1/64 iter)", d_out); run2<133>("cell B: exec-masked v_or packing (18 instr per cell)", d_out);
     return 0;
 }
