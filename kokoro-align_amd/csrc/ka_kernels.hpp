@@ -184,27 +184,98 @@ __device__ __forceinline__ void band_rebuild_one(BandMasks &mk, uint32_t lo, uin
     if constexpr (K < 15) band_rebuild_one<K + 1>(mk, lo, hi);
 }
 __device__ __forceinline__ void band_rebuild(BandMasks &mk, uint32_t lo, uint32_t hi) { band_rebuild_one<0>(mk, lo, hi); }
+// One position enters or leaves the band: flip its lane bit in the mask of its cell index (p & 15).
+// The 16-way dispatch is hand-written: a binary tree of s_bitcmp1 / s_cbranch_scc1 (10 scalar instructions
+// executed per call).  Any C++ formulation (switch, nested ifs, 16 compare-selects) is blown up by the
+// compiler's CFG structuriser / 64-bit select lowering to 130-250 scalar instructions per call, and this
+// path runs every few frames: it cost 14 % of the forward kernel.
 __device__ __forceinline__ void band_toggle(BandMasks &mk, uint32_t p)
 {
     const uint64_t bit = 1ull << ((p >> 4) & 63u);
-    switch (p & 15u) {
-    case 0: mk.m0 ^= bit; break;
-    case 1: mk.m1 ^= bit; break;
-    case 2: mk.m2 ^= bit; break;
-    case 3: mk.m3 ^= bit; break;
-    case 4: mk.m4 ^= bit; break;
-    case 5: mk.m5 ^= bit; break;
-    case 6: mk.m6 ^= bit; break;
-    case 7: mk.m7 ^= bit; break;
-    case 8: mk.m8 ^= bit; break;
-    case 9: mk.m9 ^= bit; break;
-    case 10: mk.m10 ^= bit; break;
-    case 11: mk.m11 ^= bit; break;
-    case 12: mk.m12 ^= bit; break;
-    case 13: mk.m13 ^= bit; break;
-    case 14: mk.m14 ^= bit; break;
-    default: mk.m15 ^= bit; break;
-    }
+    const uint32_t k = p & 15u;
+    asm volatile(
+        "s_bitcmp1_b32 %16, 3\n\t"
+        "s_cbranch_scc1 .Lka_8_16_%=\n\t"
+        "s_bitcmp1_b32 %16, 2\n\t"
+        "s_cbranch_scc1 .Lka_4_8_%=\n\t"
+        "s_bitcmp1_b32 %16, 1\n\t"
+        "s_cbranch_scc1 .Lka_2_4_%=\n\t"
+        "s_bitcmp1_b32 %16, 0\n\t"
+        "s_cbranch_scc1 .Lka_1_2_%=\n\t"
+        "s_xor_b64 %0, %0, %17\n\t"
+        "s_branch .Lka_end_%=\n\t"
+        ".Lka_1_2_%=:\n\t"
+        "s_xor_b64 %1, %1, %17\n\t"
+        "s_branch .Lka_end_%=\n\t"
+        ".Lka_2_4_%=:\n\t"
+        "s_bitcmp1_b32 %16, 0\n\t"
+        "s_cbranch_scc1 .Lka_3_2_%=\n\t"
+        "s_xor_b64 %2, %2, %17\n\t"
+        "s_branch .Lka_end_%=\n\t"
+        ".Lka_3_2_%=:\n\t"
+        "s_xor_b64 %3, %3, %17\n\t"
+        "s_branch .Lka_end_%=\n\t"
+        ".Lka_4_8_%=:\n\t"
+        "s_bitcmp1_b32 %16, 1\n\t"
+        "s_cbranch_scc1 .Lka_6_4_%=\n\t"
+        "s_bitcmp1_b32 %16, 0\n\t"
+        "s_cbranch_scc1 .Lka_5_2_%=\n\t"
+        "s_xor_b64 %4, %4, %17\n\t"
+        "s_branch .Lka_end_%=\n\t"
+        ".Lka_5_2_%=:\n\t"
+        "s_xor_b64 %5, %5, %17\n\t"
+        "s_branch .Lka_end_%=\n\t"
+        ".Lka_6_4_%=:\n\t"
+        "s_bitcmp1_b32 %16, 0\n\t"
+        "s_cbranch_scc1 .Lka_7_2_%=\n\t"
+        "s_xor_b64 %6, %6, %17\n\t"
+        "s_branch .Lka_end_%=\n\t"
+        ".Lka_7_2_%=:\n\t"
+        "s_xor_b64 %7, %7, %17\n\t"
+        "s_branch .Lka_end_%=\n\t"
+        ".Lka_8_16_%=:\n\t"
+        "s_bitcmp1_b32 %16, 2\n\t"
+        "s_cbranch_scc1 .Lka_12_8_%=\n\t"
+        "s_bitcmp1_b32 %16, 1\n\t"
+        "s_cbranch_scc1 .Lka_10_4_%=\n\t"
+        "s_bitcmp1_b32 %16, 0\n\t"
+        "s_cbranch_scc1 .Lka_9_2_%=\n\t"
+        "s_xor_b64 %8, %8, %17\n\t"
+        "s_branch .Lka_end_%=\n\t"
+        ".Lka_9_2_%=:\n\t"
+        "s_xor_b64 %9, %9, %17\n\t"
+        "s_branch .Lka_end_%=\n\t"
+        ".Lka_10_4_%=:\n\t"
+        "s_bitcmp1_b32 %16, 0\n\t"
+        "s_cbranch_scc1 .Lka_11_2_%=\n\t"
+        "s_xor_b64 %10, %10, %17\n\t"
+        "s_branch .Lka_end_%=\n\t"
+        ".Lka_11_2_%=:\n\t"
+        "s_xor_b64 %11, %11, %17\n\t"
+        "s_branch .Lka_end_%=\n\t"
+        ".Lka_12_8_%=:\n\t"
+        "s_bitcmp1_b32 %16, 1\n\t"
+        "s_cbranch_scc1 .Lka_14_4_%=\n\t"
+        "s_bitcmp1_b32 %16, 0\n\t"
+        "s_cbranch_scc1 .Lka_13_2_%=\n\t"
+        "s_xor_b64 %12, %12, %17\n\t"
+        "s_branch .Lka_end_%=\n\t"
+        ".Lka_13_2_%=:\n\t"
+        "s_xor_b64 %13, %13, %17\n\t"
+        "s_branch .Lka_end_%=\n\t"
+        ".Lka_14_4_%=:\n\t"
+        "s_bitcmp1_b32 %16, 0\n\t"
+        "s_cbranch_scc1 .Lka_15_2_%=\n\t"
+        "s_xor_b64 %14, %14, %17\n\t"
+        "s_branch .Lka_end_%=\n\t"
+        ".Lka_15_2_%=:\n\t"
+        "s_xor_b64 %15, %15, %17\n\t"
+        "s_branch .Lka_end_%=\n\t"
+        ".Lka_end_%=:\n\t"
+        : "+s"(mk.m0), "+s"(mk.m1), "+s"(mk.m2), "+s"(mk.m3), "+s"(mk.m4), "+s"(mk.m5), "+s"(mk.m6), "+s"(mk.m7),
+          "+s"(mk.m8), "+s"(mk.m9), "+s"(mk.m10), "+s"(mk.m11), "+s"(mk.m12), "+s"(mk.m13), "+s"(mk.m14), "+s"(mk.m15)
+        : "s"(k), "s"(bit)
+        : "scc");
 }
 // bits 0,2,..,2(n-1)
 __device__ __forceinline__ uint32_t pair_mask(int n)
@@ -455,9 +526,9 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                 }
                 // D. lane masks of frame t+1
                 if (nlo != lo || nhi != hi) {
-                    if ((nhi - hi) + (nlo - lo) <= 6u) {
-                        for (uint32_t p = hi; p < nhi; ++p) band_toggle(mk, p);
-                        for (uint32_t p = lo; p < nlo; ++p) band_toggle(mk, p);
+                    if (nhi - hi <= 1u && nlo - lo <= 1u) {
+                        if (nhi != hi) band_toggle(mk, hi);
+                        if (nlo != lo) band_toggle(mk, lo);
                     } else {
                         band_rebuild(mk, nlo, nhi);
                     }
