@@ -1018,14 +1018,24 @@ __global__ __launch_bounds__(256) void gather_outputs_kernel(const Lattice *__re
     gci32_t labx = (gci32_t)d.labx;
     gcf32_t lp = (gcf32_t)d.lp;
     const size_t ld = (size_t)d.ld;
+    // three dependent loads per frame (position -> label -> score): keep all four frames of a thread in
+    // flight at each stage before anything is stored
+    int t[4], pp[4], lab[4];
+    float sc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int t = blockIdx.x * 1024 + i * 256 + threadIdx.x;
-        if (t < T) {
-            const int pp = path[t];
-            const int lab = (pp & 1) ? (labx[pp >> 1] >> 2) : 0;
-            ((gi32_t)d.lab_out)[t] = lab;
-            ((gf32_t)d.sc_out)[t] = lp[(size_t)t * ld + lab];
+        t[i] = blockIdx.x * 1024 + i * 256 + threadIdx.x;
+        pp[i] = t[i] < T ? path[t[i]] : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lab[i] = (pp[i] & 1) ? (labx[pp[i] >> 1] >> 2) : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sc[i] = t[i] < T ? lp[(size_t)t[i] * ld + lab[i]] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (t[i] < T) {
+            ((gi32_t)d.lab_out)[t[i]] = lab[i];
+            ((gf32_t)d.sc_out)[t[i]] = sc[i];
         }
     }
 }
