@@ -60,7 +60,7 @@ size_t lattice_ws_bytes(const Shape &sh)
 {
     size_t b = align_up((size_t)sh.labx_len * 4);
     if (sh.fast) {
-        b += align_up((size_t)sh.T * 256);
+        b += align_up((((size_t)sh.T + 3) / 4) * 1024);
     } else {
         b += align_up((size_t)sh.T * (size_t)sh.W);
         b += align_up((size_t)sh.L * 2 * sizeof(float) + (size_t)sh.L * 2);
@@ -258,7 +258,7 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
         cv[i].labx = off;
         off += align_up((size_t)sh[i].labx_len * 4);
         cv[i].bp = off;
-        off += sh[i].fast ? align_up((size_t)sh[i].T * 256) : align_up((size_t)sh[i].T * (size_t)sh[i].W);
+        off += sh[i].fast ? align_up((((size_t)sh[i].T + 3) / 4) * 1024) : align_up((size_t)sh[i].T * (size_t)sh[i].W);
         cv[i].col = off;
         if (!sh[i].fast) off += align_up((size_t)sh[i].L * 2 * sizeof(float) + (size_t)sh[i].L * 2);
         if (mem == KA_MEM_HOST) {

@@ -50,13 +50,15 @@ constexpr int kStatusBadLabel = -5;
 
 constexpr int kSlots = 1024;        // 64 lanes x 16 cells
 constexpr int kFastMaxBand = 1009;  // kSlots - 15: widest band the w16 layout can hold
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kRowDepth = 4;        // log-prob rows in flight per wave
+static_assert(kRowDepth == 4, "the frame loop is unrolled by the 4 frames of a back-pointer group");
 
 struct Lattice {
     const float *lp;        // [T, ld] log-probs (device)
     const int32_t *labels;  // [S] caller labels (device)
     int32_t *labx;          // [labx_len] 4*label of odd position 2i+1, zero padded (workspace)
-    void *bp;               // w16: uint32 [T][64]; generic: uint8 [T][W]
+    void *bp;               // w16: uint32 [ceil(T/4)][64 blocks][4 frames]; generic: uint8 [T][W]
     float *col;             // generic only: 2 x L float scores followed by 2 x L present bytes
     int32_t *path;          // [T] outputs (device)
     int32_t *lab_out;
@@ -303,9 +305,13 @@ __device__ __forceinline__ uint64_t feq(float a, float b) { return __builtin_amd
 // Cell update.  m = max over the allowed moves (one v_max3 [+ v_max]); the back-pointer is the
 // FIRST move whose candidate equals m (np.argmax semantics, align.py:83) - found with equality
 // compares against m, whose lane masks are combined on the scalar unit.
-// Back-pointer code stored per cell (2 bits, decoded by bp_decode() in the backtrace):
-//   blank cell (moves {0,1,3}):  hi = (c0==m), lo = (c1==m)            -> 0 if hi, else 1 if lo, else 3
-//   label cell (moves {0,1,2,3}): hi = e0|e1,  lo = e0 | (e2 & ~e1)    -> (1,1)=0 (1,0)=1 (0,1)=2 (0,0)=3
+// Back-pointer code stored per cell (2 bits):
+//   label cell (moves {0,1,2,3}): hi = e0|e1,  lo = e0 | (e2 & ~e1)    -> code = 3 - move
+//   blank cell (moves {0,1,3}):   hi = e0,     lo = e1                 -> 0 if hi, else 1 if lo, else 3
+// The blank code is the two compare masks as they come (no scalar work in the forward kernel, where it
+// costs time); the backtrace turns it into 3 - move with a few bit-parallel VALU operations per loaded
+// dword (blank_to_uniform) and then decodes every cell with ONE scalar instruction, move = 3 & ~code:
+// its scalar chain is what bounds that kernel.
 // one blank cell (even position): move 2 is vetoed for blanks (align.py:80-81)
 template <int M>
 __device__ __forceinline__ void cell_blank(float a0, float a1, float a3, float e, float &m, uint32_t &word)
@@ -313,16 +319,17 @@ __device__ __forceinline__ void cell_blank(float a0, float a1, float a3, float e
     const float c0 = a0 + e;
     if constexpr (M == 1) {
         m = c0;
-        word = (word << 2) | 2u;   // hi=1: move 0
+        word = (word << 2) | 3u;   // (1,1): move 0
     } else {
         const float c1 = a1 + e;
         if constexpr (M <= 3) {
             m = __builtin_fmaxf(c0, c1);
+            word = (shl1_in(word, feq(c0, m)) << 1) | 1u;   // (e0, 1): c1 == m whenever c0 != m
         } else {
             const float c3 = a3 + e;
             m = __builtin_fmaxf(__builtin_fmaxf(c0, c1), c3);
+            word = shl1_in(shl1_in(word, feq(c0, m)), feq(c1, m));   // (e0, e1): converted by the backtrace
         }
-        word = shl1_in(shl1_in(word, feq(c0, m)), feq(c1, m));
     }
 }
 // one label cell (odd position): moves 0..M-1; move 2 vetoed when the label VALUE is 0
@@ -357,14 +364,15 @@ __device__ __forceinline__ void cell_label(float a0, float a1, float a2, float a
         }
     }
 }
-// number of positions to step back, from the 2-bit code of a cell (see cell_blank / cell_label)
-__device__ __forceinline__ int bp_decode(uint32_t code, int pos_is_label)
+// stored dword (16 cells) -> every cell coded as 3 - move: the blank cells (even cells: bit pairs 4i+1,4i)
+// go from (e0, e1) to (e0|e1, e0)
+__device__ __forceinline__ uint32_t blank_to_uniform(uint32_t x)
 {
-    const int hi = (code >> 1) & 1, lo = code & 1;
-    const int label_mv = hi ? (lo ? 0 : 1) : (lo ? 2 : 3);
-    const int blank_mv = hi ? 0 : (lo ? 1 : 3);
-    return pos_is_label ? label_mv : blank_mv;
+    const uint32_t h = (x >> 1) & 0x11111111u, l = x & 0x11111111u;
+    return (x & 0xCCCCCCCCu) | ((h | l) << 1) | h;
 }
+// number of positions to step back, from the uniform 2-bit code of a cell
+__device__ __forceinline__ int bp_decode(uint32_t code) { return (int)(3u & ~code); }
 // a cell's state is live after the frame iff it is in the band and (it moved in from a live
 // state = any move > 0, or it stayed on a live state).  "move == 0" per cell, bit-parallel on
 // the packed word (bit 2k+1 = hi, bit 2k = lo; even cells are blanks, odd cells labels):
@@ -377,21 +385,30 @@ __device__ __forceinline__ uint32_t moved_pairs(uint32_t word)
 }
 
 // cells 15..0 of one frame, in place (descending k: cell k reads the old k-1..k-3)
+// The emission register of a label cell is refilled for the NEXT frame (ds_bpermute of the next
+// row) right after the cell has consumed it: one set of 8 emission registers, and a whole frame of
+// other work between a gather and its use.
 template <int M, bool ZL, int K>
-__device__ __forceinline__ void frame_cells(float (&sc)[16], float h1, float h2, float h3, const float (&ec)[8],
-                                            const float (&vz)[8], float e0, BandMasks &mk, float NINF, uint32_t &word)
+__device__ __forceinline__ void frame_cells(float (&sc)[16], float h1, float h2, float h3, float (&ec)[8],
+                                            const float (&vz)[8], float e0, BandMasks &mk, float NINF, uint32_t &word,
+                                            const int (&la)[8], float next_row)
 {
     const float a0 = sc[K];
     const float a1 = K >= 1 ? sc[K >= 1 ? K - 1 : 0] : h1;
     const float a2 = K >= 2 ? sc[K >= 2 ? K - 2 : 0] : (K == 1 ? h1 : h2);
     const float a3 = K >= 3 ? sc[K >= 3 ? K - 3 : 0] : (K == 2 ? h1 : (K == 1 ? h2 : h3));
     float m;
-    if constexpr (K & 1)
+    if constexpr (K & 1) {
         cell_label<M, ZL>(a0, a1, a2, a3, ec[K >> 1], vz[K >> 1], m, word);
-    else
+        ec[K >> 1] = bperm(la[K >> 1], next_row);
+    } else {
         cell_blank<M>(a0, a1, a3, e0, m, word);
+    }
     sc[K] = select_by_mask(NINF, m, mk.at<K>());
-    if constexpr (K > 0) frame_cells<M, ZL, K - 1>(sc, h1, h2, h3, ec, vz, e0, mk, NINF, word);
+    // keep the cells in program order, four at a time: left alone, the scheduler hoists the next frame's
+    // gathers and interleaves all 16 cells, which costs ~16 VGPRs and ~60 spilled SGPRs
+    if constexpr (K % 4 == 0) __builtin_amdgcn_sched_barrier(0);
+    if constexpr (K > 0) frame_cells<M, ZL, K - 1>(sc, h1, h2, h3, ec, vz, e0, mk, NINF, word, la, next_row);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -448,17 +465,18 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
     // operations (2 stores + 2 loads); the first D rows have fewer behind them, so land them all.
 #pragma unroll
     for (int i = 0; i < D; ++i) row_wait<0>(rows[i]);
-    // emissions, double-buffered by frame parity: e[t&1] is used by frame t while e[(t+1)&1]
-    // is being gathered for frame t+1
-    float e[2][8], e0[2];
+    // emissions of the label cells: e[i] holds frame t's value until cell 2i+1 has used it, then
+    // frame t+1's (see frame_cells); the blank emission is a scalar, double-buffered by frame parity
+    float e[8], e0[2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) e[0][i] = bperm(la[i], rows[0]);
+    for (int i = 0; i < 8; ++i) e[i] = bperm(la[i], rows[0]);
     e0[0] = first_lane(rows[0]);
 
     const uint32_t *bp = reinterpret_cast<const uint32_t *>(d.bp);   // wave-uniform row base
-    const uint32_t lane_store_off = (uint32_t)lane * 4u;
+    const uint32_t lane_store_off = (uint32_t)lane * 16u;   // back-pointers: [t/4][block][t%4] dwords
 
     for (uint32_t tb = 0; tb < T; tb += D) {
+        u32x4 words = {0u, 0u, 0u, 0u};     // back-pointer words of the 4 frames of this group
 #pragma unroll
         for (int dd = 0; dd < D; ++dd) {
             const uint32_t t = tb + dd;
@@ -487,16 +505,12 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                     }
                     relabeled = true;
                 }
-                // B. emissions of frame t+1 (independent of the scores: issued one frame ahead)
-                {
-                    // row t+1 was issued D-1 frames ago; since then (D-2) frames each issued one
-                    // back-pointer store and one row load (rare label reloads only add younger ops)
-                    row_wait<2 * (D - 2)>(rows[(dd + 1) % D]);
-                    const float rn = rows[(dd + 1) % D];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) e[(dd + 1) & 1][i] = bperm(la[i], rn);
-                    e0[(dd + 1) & 1] = first_lane(rn);
-                }
+                // B. row t+1 (its emissions are gathered while frame t is computed).  It was issued D-1
+                // frames ago; since then (D-2) frames each issued one row load, and the group store of
+                // frame 4k+3 lies in between for dd = 0 and 1 (rare label reloads only add younger ops)
+                if (dd < 2) row_wait<D - 1>(rows[(dd + 1) % D]); else row_wait<D - 2>(rows[(dd + 1) % D]);
+                const float rn = rows[(dd + 1) % D];
+                e0[(dd + 1) & 1] = first_lane(rn);
                 // C. frame t
                 float h1 = wave_ror1(sc[15]), h2 = wave_ror1(sc[14]), h3 = wave_ror1(sc[13]);
                 if (__builtin_expect(pend_reset, 0)) {
@@ -514,9 +528,13 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                     pres2 = reset_lane ? 0u : pres2;
                 }
                 uint32_t word = 0;
-                frame_cells<M, ZL, 15>(sc, h1, h2, h3, e[dd & 1], vz, e0[dd & 1], mk, NINF, word);
-                // saddr (uniform row pointer) + voffset (lane*4): no per-lane 64-bit address registers
-                asm volatile("global_store_dword %0, %1, %2" : : "v"(lane_store_off), "v"(word), "s"(bp + (size_t)t * 64) : "memory");
+                frame_cells<M, ZL, 15>(sc, h1, h2, h3, e, vz, e0[dd & 1], mk, NINF, word, la, rn);
+                words[dd] = word;
+                // one 16-byte store per lane per 4 frames (the last group may be partial: the buffer is
+                // padded to whole groups).  saddr (uniform pointer to the group) + voffset (lane*16):
+                // no per-lane 64-bit address registers
+                if (dd == D - 1 || t + 1 == T)
+                    asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(lane_store_off), "v"(words), "s"(bp + (size_t)tb * 64) : "memory");
                 // live <=> in band and (moved in from a live state, or stayed on a live state)
                 pres2 = (pres2 | moved_pairs(word)) & band2;
                 // prefetch the row of frame t+D
@@ -733,8 +751,9 @@ __device__ __forceinline__ void forward_wg4(const Lattice &d, int32_t *meta)
     e0[0] = first_lane(rows[0]);
 
     const uint32_t *bp = reinterpret_cast<const uint32_t *>(d.bp);
-    const uint32_t store_off = (uint32_t)sub * 4u;       // dword (tid>>2) of the frame's 64-dword row
+    const uint32_t store_off = (uint32_t)tid * 4u;       // [t/4][block = tid>>2][t%4 = tid&3] dwords: thread tid keeps frame tid&3
     const int prev_wave = (int)((wv + 3u) & 3u);
+    uint32_t keep = 0;
 
     if (lane == 63) {
         s_halo[0][wv][0] = NINF; s_halo[0][wv][1] = NINF; s_halo[0][wv][2] = NINF; s_halo[0][wv][3] = 0.0f;
@@ -769,7 +788,7 @@ __device__ __forceinline__ void forward_wg4(const Lattice &d, int32_t *meta)
                 }
                 // B. emissions of frame t+1
                 {
-                    row_wait<2 * (D - 2)>(rows[(dd + 1) % D]);
+                    if (dd < 2) row_wait<D - 1>(rows[(dd + 1) % D]); else row_wait<D - 2>(rows[(dd + 1) % D]);   // as in forward_w16
                     const float rn = rows[(dd + 1) % D];
                     e[(dd + 1) & 1][0] = bperm(la[0], rn);
                     e[(dd + 1) & 1][1] = bperm(la[1], rn);
@@ -805,16 +824,18 @@ __device__ __forceinline__ void forward_wg4(const Lattice &d, int32_t *meta)
                     s_halo[par ^ 1][wv][3] = relabel_lane ? 1.0f : 0.0f;
                 }
                 {
-                    const uint32_t hib = (word >> 1) & 0x55u, lob = word & 0x55u;
-                    const uint32_t stay = hib & (lob | 0x11u);
+                    const uint32_t stay = ((word >> 1) & 0x55u) & ((word & 0x55u) | 0x11u);
                     pres2 = (pres2 | (~stay & 0x55u)) & band2;
                 }
-                // 4 threads x 8 bits -> the block's dword (same layout as w16), stored by the block's first thread
+                // 4 threads x 8 bits -> the block's dword (same layout as w16); thread k of the 4 keeps frame 4g+k
                 uint32_t x = word << (8 * quad);
                 x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
                 x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-                if (quad == 0)
-                    asm volatile("global_store_dword %0, %1, %2" : : "v"(store_off), "v"(x), "s"(bp + (size_t)t * 64) : "memory");
+                keep = quad == dd ? x : keep;
+                // the 256 threads store the 4 frames of the group as one contiguous KB (the last group
+                // may be partial: the buffer is padded to whole groups)
+                if (dd == D - 1 || t + 1 == T)
+                    asm volatile("global_store_dword %0, %1, %2" : : "v"(store_off), "v"(keep), "s"(bp + (size_t)tb * 64) : "memory");
                 {
                     const uint32_t tt = t + D < T ? t + D : T - 1;
                     rows[dd] = row_load(lane_off, lp + (size_t)tt * ld);
@@ -894,10 +915,11 @@ __global__ __launch_bounds__(256) void forward_wg4_kernel(const Lattice *__restr
 //
 // The walk is a scalar chain: word = v_readlane(row, lane(p)) -> 2 bits -> p -= bits.
 // A path moves at most 3 positions per frame, so the 32 frames of a chunk only ever touch the
-// 16 blocks (lanes) below the position known one chunk earlier: instead of whole 256-B rows the
-// kernel reads a 64-B window per frame (4x less HBM traffic, the kernel is HBM-bound in batched
-// runs), laid out 4 frames x 16 dwords per VGPR, 8 VGPRs per chunk, and prefetches the next
-// chunk's window while the current chunk is walked.
+// 16 blocks below the position known one chunk earlier: instead of whole rows the kernel reads
+// a 16-block window (4x less HBM traffic, the kernel is HBM-bound in batched runs).  The
+// back-pointers are stored [t/4][block][t%4], so the window of 4 frames is 256 contiguous bytes =
+// one dword per lane (lane = 16*(t%4) + block_in_window), 8 VGPRs per chunk; the next chunk's
+// window is prefetched while the current chunk is walked.
 // ---------------------------------------------------------------------------------------
 constexpr int kBtChunk = 32;                 // frames per chunk
 constexpr int kBtReach = 3 * 2 * kBtChunk;   // positions a path can drop over two chunks
@@ -917,14 +939,14 @@ __device__ __forceinline__ void bt_load_guarded(uint32_t (&r)[8], gcu32_t bp_bas
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int f = 4 * q + fr;
-        r[q] = f < n ? bp_base[(size_t)(t0 + f) * 64 + col] : 0u;
+        r[q] = f < n ? bp_base[(size_t)(t0 + 4 * q) * 64 + col * 4 + fr] : 0u;
     }
 }
 // full 32-frame chunk, loads issued from inline asm (not tracked by hipcc: it would drain vmcnt(0)
 // before the walk and serialise the prefetch); pair with bt_wait<N>()
 __device__ __forceinline__ void bt_load_async(uint32_t (&r)[8], const char *chunk_base /* uniform: row t0 */, int w0, int lane)
 {
-    const uint32_t voff = (uint32_t)(lane >> 4) * 256u + (uint32_t)((w0 + (lane & 15)) & 63) * 4u;
+    const uint32_t voff = (uint32_t)((w0 + (lane & 15)) & 63) * 16u + (uint32_t)(lane >> 4) * 4u;
     const char *hi = chunk_base + 4096;
     asm volatile("global_load_dword %0, %4, %5\n\t"
                  "global_load_dword %1, %4, %5 offset:1024\n\t"
@@ -945,21 +967,24 @@ __device__ __forceinline__ void bt_wait(uint32_t (&r)[8])
                  : "i"(N) : "memory");
 }
 // One chunk of the walk.  q = p - 16*w0 is the position relative to the window (0..255), so the
-// dependent chain per frame is: q>>4 -> |lane group -> v_readlane -> >>2(q&15) -> &3 -> q -= bits.
+// dependent chain per frame is: q>>4 -> |lane group -> v_readlane -> >>2(q&15) -> 3&~code -> q -= move.
 template <bool FULL>
 __device__ __forceinline__ void bt_walk(const uint32_t (&r)[8], int n, int w0, int &p, int &pathv)
 {
     int q = p - 16 * w0;
     const int base = 16 * w0;
+    uint32_t rr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rr[i] = blank_to_uniform(r[i]);
 #pragma unroll
     for (int f = kBtChunk - 1; f >= 0; --f) {
         if (FULL || f < n) {
-            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)r[f >> 2], (q >> 4) | ((f & 3) * 16));
-            const int pos = q + base;
-            asm("v_writelane_b32 %0, %1, %2" : "+v"(pathv) : "s"(pos), "i"(f));  // pathv[lane f] = position
-            q -= bp_decode(w >> ((q * 2) & 31), q & 1);   // 16*w0 is even: q has the parity of the position
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)rr[f >> 2], (q >> 4) | ((f & 3) * 16));
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(pathv) : "s"(q), "i"(f));  // pathv[lane f] = position - base
+            q -= bp_decode(w >> ((q * 2) & 31));
         }
     }
+    pathv += base;
     p = q + base;
 }
 
