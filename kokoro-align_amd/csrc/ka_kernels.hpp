@@ -913,51 +913,58 @@ __global__ __launch_bounds__(256) void forward_wg4_kernel(const Lattice *__restr
 // ---------------------------------------------------------------------------------------
 // backtrace (best_path), one wavefront per lattice; outputs are gathered by gather_outputs_kernel
 //
-// The walk is a scalar chain: word = v_readlane(row, lane(p)) -> 2 bits -> p -= bits.
-// A path moves at most 3 positions per frame, so the 32 frames of a chunk only ever touch the
-// 16 blocks below the position known one chunk earlier: instead of whole rows the kernel reads
-// a 16-block window (4x less HBM traffic, the kernel is HBM-bound in batched runs).  The
-// back-pointers are stored [t/4][block][t%4], so the window of 4 frames is 256 contiguous bytes =
-// one dword per lane (lane = 16*(t%4) + block_in_window), 8 VGPRs per chunk; the next chunk's
-// window is prefetched while the current chunk is walked.
+// The walk is a scalar chain: word = v_readlane(chunk register, lane(p)) -> 2 bits -> p -= move.
+// A path moves at most 3 positions per frame, so the frames of a chunk only ever touch the few
+// blocks below the position known one chunk earlier: instead of whole 1-KB groups the kernel
+// reads a window of kBtBlocks blocks (8 of 64 for 16-frame chunks: 8x less HBM traffic; the
+// kernel is HBM- and scalar-unit-bound in batched runs).  The back-pointers are stored
+// [t/4][block][t%4], so the window of 4 frames is contiguous (128 B), one dword per lane; the
+// next chunk's window is prefetched while the current chunk is walked.
 // ---------------------------------------------------------------------------------------
-constexpr int kBtChunk = 32;                 // frames per chunk
-constexpr int kBtReach = 3 * 2 * kBtChunk;   // positions a path can drop over two chunks
+#ifndef KA_BT_CHUNK
+#define KA_BT_CHUNK 16
+#endif
+constexpr int kBtChunk = KA_BT_CHUNK;                  // frames per chunk (16 or 32)
+constexpr int kBtReach = 3 * 2 * kBtChunk;             // positions a path can drop over two chunks
+constexpr int kBtBlocks = kBtChunk / 2;                // window width in blocks: 16*kBtBlocks >= kBtReach + 16 + 15
+constexpr int kBtRegs = kBtChunk * kBtBlocks / 64;     // VGPRs per chunk: one dword per (frame, window block)
+constexpr int kBtGroupsPerReg = 16 / kBtBlocks;        // 4-frame groups held by one VGPR
+static_assert(kBtChunk == 16 || kBtChunk == 32, "lane layout below");
+static_assert(16 * kBtBlocks >= kBtReach + 31, "window too narrow for the prefetch distance");
 
-// first block of the 16-block window that covers every position the path can take in the
-// chunk AFTER the one that is entered at position p_entry
+// first block of the window that covers every position the path can take in the chunk AFTER
+// the one that is entered at position p_entry
 __device__ __forceinline__ int bt_window(int p_entry)
 {
     const int lo = p_entry - kBtReach;
     return (lo > 0 ? lo : 0) >> 4;
 }
-// (possibly partial) chunk, compiler-tracked loads: used once per lattice for the tail chunk
-__device__ __forceinline__ void bt_load_guarded(uint32_t (&r)[8], gcu32_t bp_base, int t0, int n, int w0, int lane)
+// Lane layout of a chunk register r[v]: lane = ((g*4 + fr) * kBtBlocks + j) holds the dword of
+// frame 4*(v*kBtGroupsPerReg + g) + fr, window block j.
+__device__ __forceinline__ uint32_t bt_lane_offset(int w0, int lane)
 {
-    const int j = lane & 15, fr = lane >> 4;
-    const int col = (w0 + j) & 63;
+    const int j = lane % kBtBlocks, fr = (lane / kBtBlocks) & 3, g = lane / (4 * kBtBlocks);
+    return (uint32_t)g * 1024u + (uint32_t)((w0 + j) & 63) * 16u + (uint32_t)fr * 4u;
+}
+// (possibly partial) chunk, compiler-tracked loads: used once per lattice for the tail chunk
+__device__ __forceinline__ void bt_load_guarded(uint32_t (&r)[kBtRegs], const char *chunk_base, int n, int w0, int lane)
+{
+    const int fr = (lane / kBtBlocks) & 3, g = lane / (4 * kBtBlocks);
+    const uint32_t voff = bt_lane_offset(w0, lane);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int f = 4 * q + fr;
-        r[q] = f < n ? bp_base[(size_t)(t0 + 4 * q) * 64 + col * 4 + fr] : 0u;
+    for (int v = 0; v < kBtRegs; ++v) {
+        const int f = 4 * (v * kBtGroupsPerReg + g) + fr;
+        r[v] = f < n ? *(gcu32_t)(chunk_base + (size_t)v * kBtGroupsPerReg * 1024 + voff) : 0u;
     }
 }
-// full 32-frame chunk, loads issued from inline asm (not tracked by hipcc: it would drain vmcnt(0)
-// before the walk and serialise the prefetch); pair with bt_wait<N>()
-__device__ __forceinline__ void bt_load_async(uint32_t (&r)[8], const char *chunk_base /* uniform: row t0 */, int w0, int lane)
+// full chunk, loads issued from inline asm (not tracked by hipcc: it would drain vmcnt(0) before
+// the walk and serialise the prefetch); pair with bt_wait<N>()
+__device__ __forceinline__ void bt_load_async(uint32_t (&r)[kBtRegs], const char *chunk_base /* uniform: group t0/4 */, int w0, int lane)
 {
-    const uint32_t voff = (uint32_t)((w0 + (lane & 15)) & 63) * 16u + (uint32_t)(lane >> 4) * 4u;
-    const char *hi = chunk_base + 4096;
-    asm volatile("global_load_dword %0, %4, %5\n\t"
-                 "global_load_dword %1, %4, %5 offset:1024\n\t"
-                 "global_load_dword %2, %4, %5 offset:2048\n\t"
-                 "global_load_dword %3, %4, %5 offset:3072"
-                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(voff), "s"(chunk_base) : "memory");
-    asm volatile("global_load_dword %0, %4, %5\n\t"
-                 "global_load_dword %1, %4, %5 offset:1024\n\t"
-                 "global_load_dword %2, %4, %5 offset:2048\n\t"
-                 "global_load_dword %3, %4, %5 offset:3072"
-                 : "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]) : "v"(voff), "s"(hi) : "memory");
+    const uint32_t voff = bt_lane_offset(w0, lane);
+#pragma unroll
+    for (int v = 0; v < kBtRegs; ++v)
+        asm volatile("global_load_dword %0, %1, %2" : "=&v"(r[v]) : "v"(voff), "s"(chunk_base + (size_t)v * kBtGroupsPerReg * 1024) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void bt_wait(uint32_t (&r)[8])
@@ -966,20 +973,27 @@ __device__ __forceinline__ void bt_wait(uint32_t (&r)[8])
                  : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
                  : "i"(N) : "memory");
 }
-// One chunk of the walk.  q = p - 16*w0 is the position relative to the window (0..255), so the
-// dependent chain per frame is: q>>4 -> |lane group -> v_readlane -> >>2(q&15) -> 3&~code -> q -= move.
+template <int N>
+__device__ __forceinline__ void bt_wait(uint32_t (&r)[2])
+{
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r[0]), "+v"(r[1]) : "i"(N) : "memory");
+}
+// One chunk of the walk.  q = p - 16*w0 is the position relative to the window, so the dependent
+// chain per frame is: q>>4 -> |lane group -> v_readlane -> >>2(q&15) -> 3&~code -> q -= move.
 template <bool FULL>
-__device__ __forceinline__ void bt_walk(const uint32_t (&r)[8], int n, int w0, int &p, int &pathv)
+__device__ __forceinline__ void bt_walk(const uint32_t (&r)[kBtRegs], int n, int w0, int &p, int &pathv)
 {
     int q = p - 16 * w0;
     const int base = 16 * w0;
-    uint32_t rr[8];
+    uint32_t rr[kBtRegs];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) rr[i] = blank_to_uniform(r[i]);
+    for (int i = 0; i < kBtRegs; ++i) rr[i] = blank_to_uniform(r[i]);
 #pragma unroll
     for (int f = kBtChunk - 1; f >= 0; --f) {
         if (FULL || f < n) {
-            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)rr[f >> 2], (q >> 4) | ((f & 3) * 16));
+            const int grp = f >> 2;
+            const int lane_base = ((grp % kBtGroupsPerReg) * 4 + (f & 3)) * kBtBlocks;
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)rr[grp / kBtGroupsPerReg], (q >> 4) | lane_base);
             asm("v_writelane_b32 %0, %1, %2" : "+v"(pathv) : "s"(q), "i"(f));  // pathv[lane f] = position - base
             q -= bp_decode(w >> ((q * 2) & 31));
         }
@@ -997,28 +1011,28 @@ __global__ __launch_bounds__(64) void backtrace_w16_kernel(const Lattice *__rest
     const char *bp = reinterpret_cast<const char *>(d.bp);
     gi32_t path = (gi32_t)d.path;
     const int T = __builtin_amdgcn_readfirstlane(d.T);
-    uint32_t cur[8], nxt[8];
-    // tail chunk [t0, T): 1..32 frames, so that every chunk below it is a full one
+    uint32_t cur[kBtRegs], nxt[kBtRegs];
+    // tail chunk [t0, T): 1..kBtChunk frames, so that every chunk below it is a full one
     int t0 = ((T - 1) / kBtChunk) * kBtChunk;
     int w = bt_window(p + 3 * kBtChunk);   // the tail chunk is entered at the end position itself
     {
         const int n = T - t0;
-        bt_load_guarded(cur, (gcu32_t)d.bp, t0, n, w, lane);
+        bt_load_guarded(cur, bp + (size_t)t0 * 256, n, w, lane);
         const int t1 = t0 > 0 ? t0 - kBtChunk : 0;
         const int wn = bt_window(p);
         bt_load_async(nxt, bp + (size_t)t1 * 256, wn, lane);   // (re-reads chunk 0 when there is no next chunk)
         int pathv = 0;
         bt_walk<false>(cur, n, w, p, pathv);
         if (lane < n) path[t0 + lane] = pathv;
-        bt_wait<1>(nxt);                    // younger than the 8 loads: the path store
+        bt_wait<1>(nxt);                    // younger than the loads: the path store
 #pragma unroll
-        for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+        for (int i = 0; i < kBtRegs; ++i) cur[i] = nxt[i];
         w = wn;
     }
     // full chunks.  Straight-line per iteration: the registers of the in-flight loads (nxt) are
     // not touched by anything between their issue and bt_wait, and never cross the back-edge.
     while (t0 > 0) {
-        t0 -= kBtChunk;                     // chunk [t0, t0+32) is in cur, window w, entered at p
+        t0 -= kBtChunk;                     // chunk [t0, t0+kBtChunk) is in cur, window w, entered at p
         const int t1 = t0 > 0 ? t0 - kBtChunk : 0;
         const int wn = bt_window(p);
         bt_load_async(nxt, bp + (size_t)t1 * 256, wn, lane);
@@ -1027,7 +1041,7 @@ __global__ __launch_bounds__(64) void backtrace_w16_kernel(const Lattice *__rest
         if (lane < kBtChunk) path[t0 + lane] = pathv;
         bt_wait<1>(nxt);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+        for (int i = 0; i < kBtRegs; ++i) cur[i] = nxt[i];
         w = wn;
     }
 }
