@@ -103,7 +103,9 @@ __device__ __forceinline__ float ninf() { return -__builtin_inff(); }
 // lane i <- lane i-1, lane 0 <- lane 63 (DPP wave_ror:1)
 __device__ __forceinline__ float wave_ror1(float x)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x13C, 0xF, 0xF, false));
+    // every lane is written (row_mask = bank_mask = 0xF, wave_ror has no invalid source lanes), so the
+    // destination needs no initial value: mov_dpp instead of update_dpp(0, ..) saves a v_mov per call
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x13C, 0xF, 0xF, false));
 }
 // 64-bit lane mask of (a > b), ordered compare
 __device__ __forceinline__ uint64_t fgt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 2 /*FCMP_OGT*/); }
@@ -476,7 +478,11 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
     const uint32_t lane_store_off = (uint32_t)lane * 16u;   // back-pointers: [t/4][block][t%4] dwords
 
     for (uint32_t tb = 0; tb < T; tb += D) {
-        u32x4 words = {0u, 0u, 0u, 0u};     // back-pointer words of the 4 frames of this group
+        // back-pointer words of the 4 frames of this group.  Frames past T leave theirs undefined (the
+        // buffer is padded to whole groups); an empty asm output costs nothing, a zero costs a v_mov.
+        uint32_t gw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm("" : "=v"(gw[i]));
 #pragma unroll
         for (int dd = 0; dd < D; ++dd) {
             const uint32_t t = tb + dd;
@@ -506,9 +512,9 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                     relabeled = true;
                 }
                 // B. row t+1 (its emissions are gathered while frame t is computed).  It was issued D-1
-                // frames ago; since then (D-2) frames each issued one row load, and the group store of
-                // frame 4k+3 lies in between for dd = 0 and 1 (rare label reloads only add younger ops)
-                if (dd < 2) row_wait<D - 1>(rows[(dd + 1) % D]); else row_wait<D - 2>(rows[(dd + 1) % D]);
+                // frames ago; since then (D-2) frames each issued one row load, and the group store that
+                // follows frame 4k+3 lies in between unless dd = 3 (rare label reloads only add younger ops)
+                if (dd < D - 1) row_wait<D - 1>(rows[(dd + 1) % D]); else row_wait<D - 2>(rows[(dd + 1) % D]);
                 const float rn = rows[(dd + 1) % D];
                 e0[(dd + 1) & 1] = first_lane(rn);
                 // C. frame t
@@ -529,12 +535,7 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                 }
                 uint32_t word = 0;
                 frame_cells<M, ZL, 15>(sc, h1, h2, h3, e, vz, e0[dd & 1], mk, NINF, word, la, rn);
-                words[dd] = word;
-                // one 16-byte store per lane per 4 frames (the last group may be partial: the buffer is
-                // padded to whole groups).  saddr (uniform pointer to the group) + voffset (lane*16):
-                // no per-lane 64-bit address registers
-                if (dd == D - 1 || t + 1 == T)
-                    asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(lane_store_off), "v"(words), "s"(bp + (size_t)tb * 64) : "memory");
+                gw[dd] = word;
                 // live <=> in band and (moved in from a live state, or stayed on a live state)
                 pres2 = (pres2 | moved_pairs(word)) & band2;
                 // prefetch the row of frame t+D
@@ -563,6 +564,12 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                 pend_reset = relabeled;
                 reset_lane = relabel_lane;
             }
+        }
+        // one 16-byte store per lane per 4 frames.  saddr (uniform pointer to the group) + voffset
+        // (lane*16): no per-lane 64-bit address registers
+        {
+            const u32x4 words = {gw[0], gw[1], gw[2], gw[3]};
+            asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(lane_store_off), "v"(words), "s"(bp + (size_t)tb * 64) : "memory");
         }
     }
 
@@ -788,7 +795,7 @@ __device__ __forceinline__ void forward_wg4(const Lattice &d, int32_t *meta)
                 }
                 // B. emissions of frame t+1
                 {
-                    if (dd < 2) row_wait<D - 1>(rows[(dd + 1) % D]); else row_wait<D - 2>(rows[(dd + 1) % D]);   // as in forward_w16
+                    if (dd < D - 1) row_wait<D - 1>(rows[(dd + 1) % D]); else row_wait<D - 2>(rows[(dd + 1) % D]);   // as in forward_w16
                     const float rn = rows[(dd + 1) % D];
                     e[(dd + 1) & 1][0] = bperm(la[0], rn);
                     e[(dd + 1) & 1][1] = bperm(la[1], rn);
@@ -832,10 +839,6 @@ __device__ __forceinline__ void forward_wg4(const Lattice &d, int32_t *meta)
                 x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
                 x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
                 keep = quad == dd ? x : keep;
-                // the 256 threads store the 4 frames of the group as one contiguous KB (the last group
-                // may be partial: the buffer is padded to whole groups)
-                if (dd == D - 1 || t + 1 == T)
-                    asm volatile("global_store_dword %0, %1, %2" : : "v"(store_off), "v"(keep), "s"(bp + (size_t)tb * 64) : "memory");
                 {
                     const uint32_t tt = t + D < T ? t + D : T - 1;
                     rows[dd] = row_load(lane_off, lp + (size_t)tt * ld);
@@ -865,6 +868,9 @@ __device__ __forceinline__ void forward_wg4(const Lattice &d, int32_t *meta)
                 __builtin_amdgcn_s_barrier();
             }
         }
+        // the 256 threads store the 4 frames of the group as one contiguous KB (the last group may be
+        // partial: the buffer is padded to whole groups)
+        asm volatile("global_store_dword %0, %1, %2" : : "v"(store_off), "v"(keep), "s"(bp + (size_t)tb * 64) : "memory");
     }
 
     // Drain the row prefetches that are still in flight (the last D frames prefetch clamped rows that are
