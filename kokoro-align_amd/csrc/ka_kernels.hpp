@@ -114,7 +114,7 @@ __device__ __forceinline__ uint32_t shl1_in(uint32_t w, uint64_t mask)
 {
     uint32_t r;
     uint64_t carry_out;
-    asm("v_addc_co_u32 %0, %1, %2, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(w), "s"(mask));
+    asm("v_addc_co_u32 %0, %1, %2, %2, %3" : "=v"(r), "=&s"(carry_out) : "v"(w), "s"(mask));
     return r;
 }
 // mask[lane] ? b : a
@@ -379,11 +379,11 @@ __device__ __forceinline__ int bp_decode(uint32_t code) { return (int)(3u & ~cod
 // state = any move > 0, or it stayed on a live state).  "move == 0" per cell, bit-parallel on
 // the packed word (bit 2k+1 = hi, bit 2k = lo; even cells are blanks, odd cells labels):
 //   blank: move 0 <=> hi;  label: move 0 <=> hi & lo
-__device__ __forceinline__ uint32_t moved_pairs(uint32_t word)
+// Only the pair-bits (even bit positions) of the result mean anything; `band2` has zeros elsewhere.
+__device__ __forceinline__ uint32_t live_pairs(uint32_t live2, uint32_t word, uint32_t band2)
 {
-    const uint32_t hi = (word >> 1) & 0x55555555u, lo = word & 0x55555555u;
-    const uint32_t stay = hi & (lo | 0x11111111u);   // 0x1111..: pair-bits of even cells (k = 0,2,4,..)
-    return ~stay & 0x55555555u;
+    const uint32_t stay = (word >> 1) & (word | 0x11111111u);   // 0x1111..: pair-bits of even cells (k = 0,2,4,..)
+    return (live2 | ~stay) & band2;
 }
 
 // cells 15..0 of one frame, in place (descending k: cell k reads the old k-1..k-3)
@@ -537,7 +537,7 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                 frame_cells<M, ZL, 15>(sc, h1, h2, h3, e, vz, e0[dd & 1], mk, NINF, word, la, rn);
                 gw[dd] = word;
                 // live <=> in band and (moved in from a live state, or stayed on a live state)
-                pres2 = (pres2 | moved_pairs(word)) & band2;
+                pres2 = live_pairs(pres2, word, band2);
                 // prefetch the row of frame t+D
                 {
                     const uint32_t tt = t + D < T ? t + D : T - 1;
@@ -831,8 +831,7 @@ __device__ __forceinline__ void forward_wg4(const Lattice &d, int32_t *meta)
                     s_halo[par ^ 1][wv][3] = relabel_lane ? 1.0f : 0.0f;
                 }
                 {
-                    const uint32_t stay = ((word >> 1) & 0x55u) & ((word & 0x55u) | 0x11u);
-                    pres2 = (pres2 | (~stay & 0x55u)) & band2;
+                    pres2 = live_pairs(pres2, word, band2);
                 }
                 // 4 threads x 8 bits -> the block's dword (same layout as w16); thread k of the 4 keeps frame 4g+k
                 uint32_t x = word << (8 * quad);
