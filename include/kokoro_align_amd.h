@@ -97,13 +97,21 @@ int ka_ctc_best_path_batch_enqueue_f32(ka_engine *e, int32_t n, const float *con
                                        float *const *best_scores, void *stream);
 int ka_batch_finish(ka_engine *e, float *total_score, int32_t *status);
 
-/* Forward-DP kernel form.  KA_MODE_WAVE: one wavefront per lattice (throughput; fills the chip from
- * ~4096 lattices).  KA_MODE_WORKGROUP: four wavefronts per lattice with an LDS hand-off per frame
- * (about 3x lower per-frame latency; for single files or a book's few dozen chapters).
- * KA_MODE_AUTO (default): WORKGROUP up to 1024 lattices per call, WAVE above.  Results are identical. */
+/* Kernel form of the fast path.
+ *   KA_MODE_WAVE        one wavefront per lattice, checkpointed (throughput; fills the chip from ~4096
+ *                       lattices): the forward kernel keeps scores only and stores the score ring every 32
+ *                       frames; the backtrace kernel recomputes the back-pointers of the ~100 cells around the
+ *                       path from those checkpoints and writes all three outputs.  Lattices whose log-probs are
+ *                       not all finite are redone by the exact kernels in the same call.
+ *   KA_MODE_WAVE_EXACT  one wavefront per lattice, every back-pointer stored (2 bits per band cell).
+ *   KA_MODE_WORKGROUP   four wavefronts per lattice with an LDS hand-off per frame (latency: a single file, a
+ *                       book's few dozen chapters); back-pointers stored.
+ *   KA_MODE_AUTO        (default) WORKGROUP up to 1024 lattices per call, WAVE above.
+ * Results are identical in every form. */
 #define KA_MODE_AUTO 0
 #define KA_MODE_WAVE 1
 #define KA_MODE_WORKGROUP 2
+#define KA_MODE_WAVE_EXACT 3
 int ka_engine_set_mode(ka_engine *e, int32_t mode);
 
 /* Per-kernel timing of the LAST enqueued batch, measured with HIP events recorded on the

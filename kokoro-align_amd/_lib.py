@@ -149,8 +149,9 @@ class Engine:
             pass
 
     def set_mode(self, mode):
-        """'auto' | 'wave' (1 wavefront per lattice) | 'workgroup' (4 wavefronts per lattice)"""
-        code = {"auto": 0, "wave": 1, "workgroup": 2}[mode] if isinstance(mode, str) else int(mode)
+        """'auto' | 'wave' (1 wavefront per lattice, checkpointed) | 'workgroup' (4 wavefronts per lattice) |
+        'wave_exact' (1 wavefront per lattice, every back-pointer stored)"""
+        code = {"auto": 0, "wave": 1, "workgroup": 2, "wave_exact": 3}[mode] if isinstance(mode, str) else int(mode)
         check(self.lib.ka_engine_set_mode(self.handle, code), "ka_engine_set_mode")
 
     def set_profiling(self, on=True):

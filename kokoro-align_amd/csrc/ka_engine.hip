@@ -119,18 +119,26 @@ int ensure_pin(ka_engine *e, size_t bytes)
     return KA_OK;
 }
 
+enum Form { kFormWorkgroup, kFormWaveExact, kFormWaveCheckpointed };
+
 template <int M>
-void launch_forward(const ka::Lattice *d_lats, int n, int32_t *d_meta, hipStream_t s, bool workgroup_form)
+void launch_forward(const ka::Lattice *d_lats, int n, int32_t *d_meta, hipStream_t s, Form form)
 {
     // two launches over the same lattices: a lattice is taken by the kernel that matches its
     // "transcript contains label 0" flag, the other one's waves exit at once
-    if (workgroup_form) {
+    if (form == kFormWorkgroup) {
         hipLaunchKernelGGL((ka::forward_wg4_kernel<M, false>), dim3(n), dim3(256), 0, s, d_lats, d_meta);
         hipLaunchKernelGGL((ka::forward_wg4_kernel<M, true>), dim3(n), dim3(256), 0, s, d_lats, d_meta);
-    } else {
-        hipLaunchKernelGGL((ka::forward_w16_kernel<M, false>), dim3(n), dim3(64), 0, s, d_lats, d_meta);
-        hipLaunchKernelGGL((ka::forward_w16_kernel<M, true>), dim3(n), dim3(64), 0, s, d_lats, d_meta);
+        return;
     }
+    if (form == kFormWaveCheckpointed) {
+        hipLaunchKernelGGL((ka::forward_ck_kernel<M, false>), dim3(n), dim3(64), 0, s, d_lats, d_meta);
+        hipLaunchKernelGGL((ka::forward_ck_kernel<M, true>), dim3(n), dim3(64), 0, s, d_lats, d_meta);
+    }
+    // exact kernels: everything (kFormWaveExact) or only what the checkpointed kernels declined
+    const int only_flagged = form == kFormWaveCheckpointed ? 1 : 0;
+    hipLaunchKernelGGL((ka::forward_w16_kernel<M, false>), dim3(n), dim3(64), 0, s, d_lats, d_meta, only_flagged);
+    hipLaunchKernelGGL((ka::forward_w16_kernel<M, true>), dim3(n), dim3(64), 0, s, d_lats, d_meta, only_flagged);
 }
 
 }  // namespace
@@ -197,7 +205,7 @@ size_t ka_workspace_bytes(int32_t n, const int64_t *T, const int64_t *S, int32_t
 int ka_engine_set_mode(ka_engine *e, int32_t mode)
 {
     if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
-    if (mode != KA_MODE_AUTO && mode != KA_MODE_WAVE && mode != KA_MODE_WORKGROUP)
+    if (mode != KA_MODE_AUTO && mode != KA_MODE_WAVE && mode != KA_MODE_WORKGROUP && mode != KA_MODE_WAVE_EXACT)
         return fail(KA_ERR_BAD_ARGS, "ka_engine_set_mode: unknown mode");
     e->mode = mode;
     return KA_OK;
@@ -341,31 +349,49 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
     if (e->profiling) KA_HIP(hipEventRecord(e->ev[0], stream));
     hipLaunchKernelGGL(ka::prep_labels_kernel, dim3(n), dim3(256), 0, stream, d_lats, d_meta);
     if (e->profiling) KA_HIP(hipEventRecord(e->ev[1], stream));
+    Form form = kFormWaveExact;
     if (n_fast > 0) {
         // few lattices: 4 wavefronts per lattice (per-frame latency); many: 1 wavefront per lattice (throughput)
         const bool wg = e->mode == KA_MODE_WORKGROUP || (e->mode == KA_MODE_AUTO && n_fast <= kAutoWorkgroupMaxLattices);
+        form = wg ? kFormWorkgroup : (e->mode == KA_MODE_WAVE_EXACT ? kFormWaveExact : kFormWaveCheckpointed);
         switch (max_move) {
-        case 1: launch_forward<1>(d_lats, n_fast, d_meta, stream, wg); break;
-        case 2: launch_forward<2>(d_lats, n_fast, d_meta, stream, wg); break;
-        case 3: launch_forward<3>(d_lats, n_fast, d_meta, stream, wg); break;
-        default: launch_forward<4>(d_lats, n_fast, d_meta, stream, wg); break;
+        case 1: launch_forward<1>(d_lats, n_fast, d_meta, stream, form); break;
+        case 2: launch_forward<2>(d_lats, n_fast, d_meta, stream, form); break;
+        case 3: launch_forward<3>(d_lats, n_fast, d_meta, stream, form); break;
+        default: launch_forward<4>(d_lats, n_fast, d_meta, stream, form); break;
         }
     }
     if (n > n_fast)
         hipLaunchKernelGGL(ka::forward_generic_kernel, dim3(n - n_fast), dim3(256), 0, stream, d_lats + n_fast, d_meta);
     if (e->profiling) KA_HIP(hipEventRecord(e->ev[2], stream));
-    if (n_fast > 0)
-        hipLaunchKernelGGL(ka::backtrace_w16_kernel, dim3(n_fast), dim3(64), 0, stream, d_lats, d_meta);
+    const int only_flagged = form == kFormWaveCheckpointed ? 1 : 0;
+    if (n_fast > 0) {
+        if (form == kFormWaveCheckpointed) {
+            switch (max_move) {
+            case 1: hipLaunchKernelGGL(ka::backtrace_rc_kernel<1>, dim3(n_fast), dim3(64), 0, stream, d_lats, d_meta); break;
+            case 2: hipLaunchKernelGGL(ka::backtrace_rc_kernel<2>, dim3(n_fast), dim3(64), 0, stream, d_lats, d_meta); break;
+            case 3: hipLaunchKernelGGL(ka::backtrace_rc_kernel<3>, dim3(n_fast), dim3(64), 0, stream, d_lats, d_meta); break;
+            default: hipLaunchKernelGGL(ka::backtrace_rc_kernel<4>, dim3(n_fast), dim3(64), 0, stream, d_lats, d_meta); break;
+            }
+        }
+        hipLaunchKernelGGL(ka::backtrace_w16_kernel, dim3(n_fast), dim3(64), 0, stream, d_lats, d_meta, only_flagged);
+    }
     if (n > n_fast)
         hipLaunchKernelGGL(ka::backtrace_generic_kernel, dim3(n - n_fast), dim3(64), 0, stream, d_lats + n_fast, d_meta);
     if (e->profiling) KA_HIP(hipEventRecord(e->ev[3], stream));
     {
+        // descriptors are sorted fast-first: [0, n_fast) may already have their outputs (checkpointed form)
         int64_t t_max = 1;
         for (int32_t i = 0; i < n; ++i) t_max = std::max<int64_t>(t_max, sh[i].T);
         const unsigned gx = (unsigned)((t_max + 1023) / 1024);
-        for (int32_t y0 = 0; y0 < n; y0 += 65535) {   // grid.y limit
+        const int32_t n_own = only_flagged ? n_fast : 0;   // lattices whose outputs the backtrace kernel wrote itself
+        for (int32_t y0 = 0; y0 < n_own; y0 += 65535) {
+            const unsigned gy = (unsigned)std::min<int32_t>(65535, n_own - y0);
+            hipLaunchKernelGGL(ka::gather_outputs_kernel, dim3(1, gy), dim3(256), 0, stream, d_lats + y0, d_meta, 1);
+        }
+        for (int32_t y0 = n_own; y0 < n; y0 += 65535) {   // grid.y limit
             const unsigned gy = (unsigned)std::min<int32_t>(65535, n - y0);
-            hipLaunchKernelGGL(ka::gather_outputs_kernel, dim3(gx, gy), dim3(256), 0, stream, d_lats + y0, d_meta);
+            hipLaunchKernelGGL(ka::gather_outputs_kernel, dim3(gx, gy), dim3(256), 0, stream, d_lats + y0, d_meta, 0);
         }
     }
     if (e->profiling) KA_HIP(hipEventRecord(e->ev[4], stream));

@@ -47,10 +47,14 @@ typedef KA_GLOBAL const v4i_t *gci4_t;
 constexpr int kStatusOk = 0;
 constexpr int kStatusEmptyBeam = -1;
 constexpr int kStatusBadLabel = -5;
+constexpr int kFlagZeroLabel = 1;   // meta flags: a transcript label is 0
+constexpr int kFlagExact = 2;       // meta flags: the checkpointed path declined this lattice (non-finite log-probs)
 
 constexpr int kSlots = 1024;        // 64 lanes x 16 cells
 constexpr int kFastMaxBand = 1009;  // kSlots - 15: widest band the w16 layout can hold
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kCkFrames = 32;       // checkpointed path: frames between stored score rings
 constexpr int kRowDepth = 4;        // log-prob rows in flight per wave
 static_assert(kRowDepth == 4, "the frame loop is unrolled by the 4 frames of a back-pointer group");
 
@@ -386,11 +390,36 @@ __device__ __forceinline__ uint32_t live_pairs(uint32_t live2, uint32_t word, ui
     return (live2 | ~stay) & band2;
 }
 
+// score-only cells (checkpointed path: the back-pointers are recomputed by backtrace_rc_kernel)
+template <int M>
+__device__ __forceinline__ float cell_blank_score(float a0, float a1, float a3, float e)
+{
+    const float c0 = a0 + e;
+    if constexpr (M == 1) return c0;
+    const float c1 = a1 + e;
+    if constexpr (M <= 3) return __builtin_fmaxf(c0, c1);
+    const float c3 = a3 + e;
+    return __builtin_fmaxf(__builtin_fmaxf(c0, c1), c3);
+}
+template <int M, bool ZL>
+__device__ __forceinline__ float cell_label_score(float a0, float a1, float a2, float a3, float e, float veto)
+{
+    const float c0 = a0 + e;
+    if constexpr (M == 1) return c0;
+    const float c1 = a1 + e;
+    if constexpr (M == 2) return __builtin_fmaxf(c0, c1);
+    float c2 = a2 + e;
+    if constexpr (ZL) c2 = __builtin_fminf(c2, veto);
+    if constexpr (M == 3) return __builtin_fmaxf(__builtin_fmaxf(c0, c1), c2);
+    const float c3 = a3 + e;
+    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(c0, c1), c2), c3);
+}
+
 // cells 15..0 of one frame, in place (descending k: cell k reads the old k-1..k-3)
 // The emission register of a label cell is refilled for the NEXT frame (ds_bpermute of the next
 // row) right after the cell has consumed it: one set of 8 emission registers, and a whole frame of
 // other work between a gather and its use.
-template <int M, bool ZL, int K>
+template <int M, bool ZL, int K, bool LITE>
 __device__ __forceinline__ void frame_cells(float (&sc)[16], float h1, float h2, float h3, float (&ec)[8],
                                             const float (&vz)[8], float e0, BandMasks &mk, float NINF, uint32_t &word,
                                             const int (&la)[8], float next_row)
@@ -401,22 +430,28 @@ __device__ __forceinline__ void frame_cells(float (&sc)[16], float h1, float h2,
     const float a3 = K >= 3 ? sc[K >= 3 ? K - 3 : 0] : (K == 2 ? h1 : (K == 1 ? h2 : h3));
     float m;
     if constexpr (K & 1) {
-        cell_label<M, ZL>(a0, a1, a2, a3, ec[K >> 1], vz[K >> 1], m, word);
+        if constexpr (LITE) m = cell_label_score<M, ZL>(a0, a1, a2, a3, ec[K >> 1], vz[K >> 1]);
+        else cell_label<M, ZL>(a0, a1, a2, a3, ec[K >> 1], vz[K >> 1], m, word);
         ec[K >> 1] = bperm(la[K >> 1], next_row);
     } else {
-        cell_blank<M>(a0, a1, a3, e0, m, word);
+        if constexpr (LITE) m = cell_blank_score<M>(a0, a1, a3, e0);
+        else cell_blank<M>(a0, a1, a3, e0, m, word);
     }
     sc[K] = select_by_mask(NINF, m, mk.at<K>());
     // keep the cells in program order, four at a time: left alone, the scheduler hoists the next frame's
     // gathers and interleaves all 16 cells, which costs ~16 VGPRs and ~60 spilled SGPRs
     if constexpr (K % 4 == 0) __builtin_amdgcn_sched_barrier(0);
-    if constexpr (K > 0) frame_cells<M, ZL, K - 1>(sc, h1, h2, h3, ec, vz, e0, mk, NINF, word, la, next_row);
+    if constexpr (K > 0) frame_cells<M, ZL, K - 1, LITE>(sc, h1, h2, h3, ec, vz, e0, mk, NINF, word, la, next_row);
 }
 
 // ---------------------------------------------------------------------------------------
 // forward DP, one wavefront per lattice
 // ---------------------------------------------------------------------------------------
-template <int M, bool ZL>
+// LITE = checkpointed path: scores only (no compares, no back-pointer packing, no liveness word);
+// the score ring is stored every kCkFrames frames and backtrace_rc_kernel recomputes the back-pointers
+// of the ~100 cells around the path.  Valid when every log-prob is finite (then live <=> score > -inf);
+// the kernel checks that and flags the lattice for the exact kernels otherwise.
+template <int M, bool ZL, bool LITE>
 __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
 {
     constexpr int D = kRowDepth;
@@ -435,6 +470,7 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
     for (int k = 0; k < 16; ++k) sc[k] = NINF;
     if (lane == 0) sc[0] = 0.0f;            // virtual state before frame 0 (align.py:57-58)
     uint32_t pres2 = lane == 0 ? 1u : 0u;   // bit 2k: cell k holds a live state
+    float absum = 0.0f;                     // LITE: sum over frames of |lp[t, lane]| (finiteness check)
     bool pend_reset = false;                // wave-uniform: some lane was re-labelled for this frame
     bool reset_lane = false;                // per lane: this lane was re-labelled
 
@@ -473,6 +509,7 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
 #pragma unroll
     for (int i = 0; i < 8; ++i) e[i] = bperm(la[i], rows[0]);
     e0[0] = first_lane(rows[0]);
+    if constexpr (LITE) absum = __builtin_fabsf(rows[0]);
 
     const uint32_t *bp = reinterpret_cast<const uint32_t *>(d.bp);   // wave-uniform row base
     const uint32_t lane_store_off = (uint32_t)lane * 16u;   // back-pointers: [t/4][block][t%4] dwords
@@ -514,9 +551,10 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                 // B. row t+1 (its emissions are gathered while frame t is computed).  It was issued D-1
                 // frames ago; since then (D-2) frames each issued one row load, and the group store that
                 // follows frame 4k+3 lies in between unless dd = 3 (rare label reloads only add younger ops)
-                if (dd < D - 1) row_wait<D - 1>(rows[(dd + 1) % D]); else row_wait<D - 2>(rows[(dd + 1) % D]);
+                if (!LITE && dd < D - 1) row_wait<D - 1>(rows[(dd + 1) % D]); else row_wait<D - 2>(rows[(dd + 1) % D]);
                 const float rn = rows[(dd + 1) % D];
                 e0[(dd + 1) & 1] = first_lane(rn);
+                if constexpr (LITE) absum += __builtin_fabsf(rn);
                 // C. frame t
                 float h1 = wave_ror1(sc[15]), h2 = wave_ror1(sc[14]), h3 = wave_ror1(sc[13]);
                 if (__builtin_expect(pend_reset, 0)) {
@@ -534,10 +572,10 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                     pres2 = reset_lane ? 0u : pres2;
                 }
                 uint32_t word = 0;
-                frame_cells<M, ZL, 15>(sc, h1, h2, h3, e, vz, e0[dd & 1], mk, NINF, word, la, rn);
+                frame_cells<M, ZL, 15, LITE>(sc, h1, h2, h3, e, vz, e0[dd & 1], mk, NINF, word, la, rn);
                 gw[dd] = word;
                 // live <=> in band and (moved in from a live state, or stayed on a live state)
-                pres2 = live_pairs(pres2, word, band2);
+                if constexpr (!LITE) pres2 = live_pairs(pres2, word, band2);
                 // prefetch the row of frame t+D
                 {
                     const uint32_t tt = t + D < T ? t + D : T - 1;
@@ -565,11 +603,19 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                 reset_lane = relabel_lane;
             }
         }
-        // one 16-byte store per lane per 4 frames.  saddr (uniform pointer to the group) + voffset
-        // (lane*16): no per-lane 64-bit address registers
-        {
+        if constexpr (!LITE) {
+            // one 16-byte store per lane per 4 frames.  saddr (uniform pointer to the group) + voffset
+            // (lane*16): no per-lane 64-bit address registers
             const u32x4 words = {gw[0], gw[1], gw[2], gw[3]};
             asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(lane_store_off), "v"(words), "s"(bp + (size_t)tb * 64) : "memory");
+        } else if (((tb + D) & (kCkFrames - 1)) == 0 && tb + D < T) {
+            // checkpoint (tb+D)/kCkFrames: the scores after frame tb+D-1, [lane][16 cells], 4 KB
+            const char *ck = reinterpret_cast<const char *>(bp) + ((size_t)((tb + D) / kCkFrames) - 1) * 4096;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {sc[4 * g], sc[4 * g + 1], sc[4 * g + 2], sc[4 * g + 3]};
+                asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" : : "v"((uint32_t)lane * 64u), "v"(v), "s"(ck), "i"(16 * g) : "memory");
+            }
         }
     }
 
@@ -579,6 +625,20 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
 #pragma unroll
     for (int i = 0; i < D; ++i) row_wait<0>(rows[i]);
 
+    int32_t *m = meta_of(meta, d.idx);
+    if constexpr (LITE) {
+        // Every partial path score is bounded by the sum of all |lp|: if each column's sum stays below
+        // 1e30 nothing can have overflowed and every live state has a finite score, so live <=> score > -inf.
+        // Otherwise (an infinity, a NaN, absurd magnitudes) hand the lattice to the exact kernels.
+        const bool ok = absum < 1e30f;
+        if (__builtin_amdgcn_ballot_w64(!ok)) {
+            if (lane == 0) atomicOr(&m[2], kFlagExact);
+            return;
+        }
+        pres2 = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) pres2 |= sc[k] != NINF ? (1u << (2 * k)) : 0u;
+    }
     // terminal state: the HIGHEST live position of frame T-1 (align.py:99-101)
     int best = -1;
     if (pres2) best = blk * 16 + ((31 - __clz((int)pres2)) >> 1);
@@ -587,7 +647,6 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
         const int o = __shfl_xor(best, off);
         best = o > best ? o : best;
     }
-    int32_t *m = meta_of(meta, d.idx);
     if (best < 0) {
         if (lane == 0) {
             m[1] = -1;
@@ -608,13 +667,23 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
 // Two kernels per max_move, launched back to back over the same lattices: ZL = the transcript
 // contains label 0 (needs the per-label veto).  A wave whose lattice belongs to the other kernel
 // exits at once.  Keeping them apart keeps the veto registers out of the common kernel.
+// only_flagged: second pass behind the checkpointed kernels, for the lattices they declined
 template <int M, bool ZL>
-__global__ __launch_bounds__(64, KA_FWD_MIN_WAVES) void forward_w16_kernel(const Lattice *__restrict__ lats, int32_t *meta)
+__global__ __launch_bounds__(64, KA_FWD_MIN_WAVES) void forward_w16_kernel(const Lattice *__restrict__ lats, int32_t *meta, int only_flagged)
 {
     const Lattice &d = lats[blockIdx.x];
-    const int zl = __builtin_amdgcn_readfirstlane(meta_of(meta, d.idx)[2] & 1);
-    if ((zl != 0) != ZL) return;
-    forward_w16<M, ZL>(d, meta);
+    const int flags = __builtin_amdgcn_readfirstlane(meta_of(meta, d.idx)[2]);
+    if (((flags & kFlagZeroLabel) != 0) != ZL) return;
+    if (only_flagged && !(flags & kFlagExact)) return;
+    forward_w16<M, ZL, false>(d, meta);
+}
+template <int M, bool ZL>
+__global__ __launch_bounds__(64, KA_FWD_MIN_WAVES) void forward_ck_kernel(const Lattice *__restrict__ lats, int32_t *meta)
+{
+    const Lattice &d = lats[blockIdx.x];
+    const int flags = __builtin_amdgcn_readfirstlane(meta_of(meta, d.idx)[2]);
+    if (((flags & kFlagZeroLabel) != 0) != ZL) return;
+    forward_w16<M, ZL, true>(d, meta);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1007,10 +1076,11 @@ __device__ __forceinline__ void bt_walk(const uint32_t (&r)[kBtRegs], int n, int
     p = q + base;
 }
 
-__global__ __launch_bounds__(64) void backtrace_w16_kernel(const Lattice *__restrict__ lats, const int32_t *meta)
+__global__ __launch_bounds__(64) void backtrace_w16_kernel(const Lattice *__restrict__ lats, const int32_t *meta, int only_flagged)
 {
     const Lattice &d = lats[blockIdx.x];
     const int lane = threadIdx.x;
+    if (only_flagged && !(__builtin_amdgcn_readfirstlane(meta[4 * (size_t)d.idx + 2]) & kFlagExact)) return;
     int p = __builtin_amdgcn_readfirstlane(meta[4 * (size_t)d.idx + 1]);
     if (p < 0) return;  // empty beam: status already set by the forward kernel
     const char *bp = reinterpret_cast<const char *>(d.bp);
@@ -1051,35 +1121,196 @@ __global__ __launch_bounds__(64) void backtrace_w16_kernel(const Lattice *__rest
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// checkpointed path, second kernel: back-pointers recomputed around the path, then walked.
+//
+// forward_ck_kernel left the score ring of every kCkFrames-th frame in HBM.  Going backwards
+// chunk by chunk (chunk = the 32 frames after a checkpoint), the path is known at the chunk's
+// last frame (position p); it drops at most 3 positions per frame, and a cell only depends on
+// positions below it, so the back-pointers the walk will read all lie in the 97 positions below
+// p, and they are exact if the chunk is recomputed forward from the checkpoint on the window
+// [p-96, p+31]: whatever is wrong at the window's low edge (unknown neighbours) climbs 3 positions
+// per frame, exactly as fast as the path can fall.  64 lanes x (one blank + one label cell); same
+// float operations in the same order as the forward kernel, so the scores are bit-identical.
+// The kernel also writes best_labels / best_scores: the chunk's log-prob rows are in registers
+// (lane v = lp[t, v]), so a score is one v_readlane - no second pass over the log-probs.
+// ---------------------------------------------------------------------------------------
+// lane i <- lane i-1, lane 0 <- fill (DPP wave_shr:1)
+__device__ __forceinline__ float wave_shr1(float x, float fill)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, x),
+                                                                 0x138, 0xF, 0xF, false));
+}
+// 8 frames x 4 bits (blank hi, blank lo, label hi, label lo): blank nibbles (e0, e1) -> (e0|e1, e0)
+__device__ __forceinline__ uint32_t rc_blank_to_uniform(uint32_t x)
+{
+    const uint32_t h = (x >> 3) & 0x11111111u, l = (x >> 2) & 0x11111111u;
+    return (x & 0x33333333u) | ((h | l) << 3) | (h << 2);
+}
+
+template <int M>
+__global__ __launch_bounds__(64) void backtrace_rc_kernel(const Lattice *__restrict__ lats, const int32_t *meta)
+{
+    const Lattice &d = lats[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int32_t *mt = meta + 4 * (size_t)d.idx;
+    if (__builtin_amdgcn_readfirstlane(mt[2]) & kFlagExact) return;   // handled by the exact kernels
+    int p = __builtin_amdgcn_readfirstlane(mt[1]);
+    if (p < 0) return;  // empty beam: status already set by the forward kernel
+    const uint32_t T = (uint32_t)__builtin_amdgcn_readfirstlane(d.T);
+    const uint32_t L = (uint32_t)__builtin_amdgcn_readfirstlane(d.L);
+    const uint32_t B = (uint32_t)__builtin_amdgcn_readfirstlane(d.beam);
+    const uint32_t halfB = B >> 1;
+    const uint32_t dq = L / T, dr = L % T;
+    const float NINF = ninf();
+    gcf32_t lp = (gcf32_t)d.lp;
+    const size_t ld = (size_t)d.ld;
+    const int col = lane < d.V ? lane : 0;
+    gci32_t labx = (gci32_t)d.labx;
+    const char *ck = reinterpret_cast<const char *>(d.bp);
+    gi32_t path = (gi32_t)d.path;
+    gi32_t lab_out = (gi32_t)d.lab_out;
+    gf32_t sc_out = (gf32_t)d.sc_out;
+
+    // floor(L*t/T) and remainder at the start of the last chunk; one chunk back = minus (32*L)/T, (32*L)%T
+    uint32_t t0 = ((T - 1) / kCkFrames) * kCkFrames;
+    uint32_t q0, r0;
+    {
+        const uint64_t prod = (uint64_t)L * t0;
+        q0 = (uint32_t)(prod / T);
+        r0 = (uint32_t)(prod % T);
+    }
+    const uint32_t D32 = (uint32_t)(((uint64_t)L * kCkFrames) / T), R32 = (uint32_t)(((uint64_t)L * kCkFrames) % T);
+
+    for (;;) {
+        const int n = (int)(T - t0 < (uint32_t)kCkFrames ? T - t0 : (uint32_t)kCkFrames);
+        const int wlo = (p > 96 ? p - 96 : 0) & ~1;
+        const int pb = wlo + 2 * lane;                       // this lane's blank position; its label position is pb+1
+        const int lab4 = labx[(size_t)(wlo >> 1) + lane];    // 4 * label of position pb+1 (zero padded past S)
+        const float veto = lab4 == 0 ? NINF : __builtin_inff();
+        float rows[kCkFrames];
+#pragma unroll
+        for (int f = 0; f < kCkFrames; ++f) {
+            const uint32_t tt = t0 + f < T ? t0 + f : T - 1;
+            rows[f] = lp[(size_t)tt * ld + col];
+        }
+        // scores after frame t0-1, limited to that frame's band
+        float sb, sl;
+        if (t0 == 0) {
+            sb = pb == 0 ? 0.0f : NINF;   // virtual state before frame 0 (align.py:57-58)
+            sl = NINF;
+        } else {
+            const char *c = ck + ((size_t)(t0 / kCkFrames) - 1) * 4096 + (size_t)((pb >> 4) & 63) * 64 + (size_t)(pb & 15) * 4;
+            const float v0 = *(gcf32_t)c, v1 = *(gcf32_t)(c + 4);
+            const uint32_t qm = r0 >= dr ? q0 - dq : q0 - dq - 1;
+            const int32_t dl = (int32_t)qm - (int32_t)halfB;
+            const uint32_t lo1 = (uint32_t)(dl > 0 ? dl : 0);
+            const uint32_t hi1 = (L - lo1 < B) ? L : lo1 + B;
+            sb = ((uint32_t)pb >= lo1 && (uint32_t)pb < hi1) ? v0 : NINF;
+            sl = ((uint32_t)pb + 1 >= lo1 && (uint32_t)pb + 1 < hi1) ? v1 : NINF;
+        }
+        // ---- forward over the chunk: scores + back-pointer codes of the window ----
+        uint32_t codes[kCkFrames / 8];
+        uint32_t q = q0, rem = r0;
+        uint64_t mask_b = 0, mask_l = 0;
+        bool band_moved = true;
+#pragma unroll
+        for (int f = 0; f < kCkFrames; ++f) {
+            if (band_moved) {
+                const int32_t dl = (int32_t)q - (int32_t)halfB;
+                const int32_t lo = dl > 0 ? dl : 0;
+                const int32_t hi = (L - (uint32_t)lo < B) ? (int32_t)L : lo + (int32_t)B;
+                const int32_t x = lo - wlo, y = hi - wlo;
+                // blank wlo+2l in [lo,hi) <=> l in [ceil(x/2), ceil(y/2));  label wlo+2l+1 <=> l in [ceil((x-1)/2), ceil((y-1)/2))
+                const auto half_up = [](int32_t v) { v = v > 0 ? v : 0; v = (v + 1) >> 1; return (uint32_t)(v < 64 ? v : 64); };
+                mask_b = lane_range(half_up(x), half_up(y));
+                mask_l = lane_range(half_up(x - 1), half_up(y - 1));
+            }
+            const float el = bperm(lab4, rows[f]);
+            const float e0 = first_lane(rows[f]);
+            const float L1 = wave_shr1(sl, NINF);    // score of pb-1
+            const float B1 = wave_shr1(sb, NINF);    // score of pb-2
+            const float L2 = wave_shr1(L1, NINF);    // score of pb-3
+            uint32_t &word = codes[f >> 3];
+            if ((f & 7) == 0) word = 0;
+            float mb, ml;
+            cell_blank<M>(sb, L1, L2, e0, mb, word);
+            cell_label<M, true>(sl, sb, L1, B1, el, veto, ml, word);
+            sb = select_by_mask(NINF, mb, mask_b);
+            sl = select_by_mask(NINF, ml, mask_l);
+            // band of the next frame
+            q += dq;
+            rem += dr;
+            band_moved = dq != 0;
+            if (rem >= T) { rem -= T; ++q; band_moved = true; }
+        }
+        // ---- walk back over the chunk ----
+#pragma unroll
+        for (int g = 0; g < kCkFrames / 8; ++g) codes[g] = rc_blank_to_uniform(codes[g]);
+        int pathv = 0, labv = 0;
+        float scv = 0.0f;
+        int qq = p - wlo;
+#pragma unroll
+        for (int f = kCkFrames - 1; f >= 0; --f) {
+            if (f < n) {
+                const int ln = qq >> 1;
+                const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)codes[f >> 3], ln) >> (4 * (7 - (f & 7)));
+                const int l4 = (qq & 1) ? __builtin_amdgcn_readlane(lab4, ln) : 0;
+                const uint32_t code = (qq & 1) ? w : (w >> 2);
+                const float sv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rows[f]), l4 >> 2));
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(pathv) : "s"(qq), "i"(f));
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(labv) : "s"(l4 >> 2), "i"(f));
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(scv) : "s"(sv), "i"(f));
+                qq -= bp_decode(code);
+            }
+        }
+        if (lane < n) {
+            path[t0 + lane] = pathv + wlo;
+            lab_out[t0 + lane] = labv;
+            sc_out[t0 + lane] = scv;
+        }
+        p = qq + wlo;
+        if (t0 == 0) break;
+        t0 -= kCkFrames;
+        q0 -= D32;
+        if (r0 < R32) { r0 += T; q0 -= 1; }
+        r0 -= R32;
+    }
+}
+
 // best_labels = lab'[best_path], best_scores[t] = lp[t, best_labels[t]]  (align.py:105-107)
-// grid: x = 1024-frame slice, y = lattice
-__global__ __launch_bounds__(256) void gather_outputs_kernel(const Lattice *__restrict__ lats, const int32_t *meta)
+// grid: x = 1024-frame slices (a block strides over them), y = lattice.  only_flagged: behind the
+// checkpointed kernels (which write these outputs themselves), for the lattices they declined.
+__global__ __launch_bounds__(256) void gather_outputs_kernel(const Lattice *__restrict__ lats, const int32_t *meta, int only_flagged)
 {
     const Lattice &d = lats[blockIdx.y];
     if (meta[4 * (size_t)d.idx + 1] < 0) return;
+    if (only_flagged && !(meta[4 * (size_t)d.idx + 2] & kFlagExact)) return;
     const int T = d.T;
     gci32_t path = (gci32_t)d.path;
     gci32_t labx = (gci32_t)d.labx;
     gcf32_t lp = (gcf32_t)d.lp;
     const size_t ld = (size_t)d.ld;
-    // three dependent loads per frame (position -> label -> score): keep all four frames of a thread in
-    // flight at each stage before anything is stored
-    int t[4], pp[4], lab[4];
-    float sc[4];
+    for (int base = blockIdx.x * 1024; base < T; base += gridDim.x * 1024) {
+        // three dependent loads per frame (position -> label -> score): keep all four frames of a thread in
+        // flight at each stage before anything is stored
+        int t[4], pp[4], lab[4];
+        float sc[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        t[i] = blockIdx.x * 1024 + i * 256 + threadIdx.x;
-        pp[i] = t[i] < T ? path[t[i]] : 0;
-    }
+        for (int i = 0; i < 4; ++i) {
+            t[i] = base + i * 256 + threadIdx.x;
+            pp[i] = t[i] < T ? path[t[i]] : 0;
+        }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) lab[i] = (pp[i] & 1) ? (labx[pp[i] >> 1] >> 2) : 0;
+        for (int i = 0; i < 4; ++i) lab[i] = (pp[i] & 1) ? (labx[pp[i] >> 1] >> 2) : 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sc[i] = t[i] < T ? lp[(size_t)t[i] * ld + lab[i]] : 0.0f;
+        for (int i = 0; i < 4; ++i) sc[i] = t[i] < T ? lp[(size_t)t[i] * ld + lab[i]] : 0.0f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (t[i] < T) {
-            ((gi32_t)d.lab_out)[t[i]] = lab[i];
-            ((gf32_t)d.sc_out)[t[i]] = sc[i];
+        for (int i = 0; i < 4; ++i) {
+            if (t[i] < T) {
+                ((gi32_t)d.lab_out)[t[i]] = lab[i];
+                ((gf32_t)d.sc_out)[t[i]] = sc[i];
+            }
         }
     }
 }

@@ -13,7 +13,7 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["wave", "workgroup"])
+@pytest.fixture(scope="module", params=["wave", "workgroup", "wave_exact"])
 def ka(request):
     """Every test runs with both forms of the forward kernel: one wavefront per lattice (throughput)
     and four wavefronts per lattice (latency).  Results must be identical."""
