@@ -54,6 +54,7 @@ constexpr int kSlots = 1024;        // 64 lanes x 16 cells
 constexpr int kFastMaxBand = 1009;  // kSlots - 15: widest band the w16 layout can hold
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int kCkFrames = 32;       // checkpointed path: frames between stored score rings
 constexpr int kRowDepth = 4;        // log-prob rows in flight per wave
 static_assert(kRowDepth == 4, "the frame loop is unrolled by the 4 frames of a back-pointer group");
@@ -151,6 +152,46 @@ template <int N>
 __device__ __forceinline__ void row_wait(float &r)
 {
     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "i"(N) : "memory");
+}
+
+// same with a count that is a constant only after loop unrolling (the switch folds away)
+__device__ __forceinline__ void row_wait_n(float &r, int n)
+{
+    switch (n) {
+    case 0: row_wait<0>(r); break;
+    case 1: row_wait<1>(r); break;
+    case 2: row_wait<2>(r); break;
+    case 3: row_wait<3>(r); break;
+    case 4: row_wait<4>(r); break;
+    case 5: row_wait<5>(r); break;
+    case 6: row_wait<6>(r); break;
+    case 7: row_wait<7>(r); break;
+    case 8: row_wait<8>(r); break;
+    case 9: row_wait<9>(r); break;
+    case 10: row_wait<10>(r); break;
+    case 11: row_wait<11>(r); break;
+    case 12: row_wait<12>(r); break;
+    case 13: row_wait<13>(r); break;
+    case 14: row_wait<14>(r); break;
+    case 15: row_wait<15>(r); break;
+    case 16: row_wait<16>(r); break;
+    case 17: row_wait<17>(r); break;
+    case 18: row_wait<18>(r); break;
+    case 19: row_wait<19>(r); break;
+    case 20: row_wait<20>(r); break;
+    case 21: row_wait<21>(r); break;
+    case 22: row_wait<22>(r); break;
+    case 23: row_wait<23>(r); break;
+    case 24: row_wait<24>(r); break;
+    case 25: row_wait<25>(r); break;
+    case 26: row_wait<26>(r); break;
+    case 27: row_wait<27>(r); break;
+    case 28: row_wait<28>(r); break;
+    case 29: row_wait<29>(r); break;
+    case 30: row_wait<30>(r); break;
+    case 31: row_wait<31>(r); break;
+    default: row_wait<0>(r); break;
+    }
 }
 
 // Lane masks of the band: m<k> has bit ((p>>4)&63) set for every p in [lo,hi) with p&15 == k.
@@ -1135,18 +1176,21 @@ __global__ __launch_bounds__(64) void backtrace_w16_kernel(const Lattice *__rest
 // The kernel also writes best_labels / best_scores: the chunk's log-prob rows are in registers
 // (lane v = lp[t, v]), so a score is one v_readlane - no second pass over the log-probs.
 // ---------------------------------------------------------------------------------------
-// lane i <- lane i-1, lane 0 <- fill (DPP wave_shr:1)
-__device__ __forceinline__ float wave_shr1(float x, float fill)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, x),
-                                                                 0x138, 0xF, 0xF, false));
-}
 // 8 frames x 4 bits (blank hi, blank lo, label hi, label lo): blank nibbles (e0, e1) -> (e0|e1, e0)
 __device__ __forceinline__ uint32_t rc_blank_to_uniform(uint32_t x)
 {
     const uint32_t h = (x >> 3) & 0x11111111u, l = (x >> 2) & 0x11111111u;
     return (x & 0x33333333u) | ((h | l) << 3) | (h << 2);
 }
+// lanes [first, first+count) of a 64-bit mask, count and first in 0..63: one s_bfm_b64
+__device__ __forceinline__ uint64_t lane_field(uint32_t count, uint32_t first)
+{
+    uint64_t m;
+    asm("s_bfm_b64 %0, %1, %2" : "=s"(m) : "s"(count), "s"(first));
+    return m;
+}
+constexpr int kRcLanes = 62;   // lanes 62 and 63 are kept at -inf: they are the "nothing below position 0" that
+                               // wave_ror hands to lanes 0 and 1 (window width 124 >= 97 + slack)
 
 template <int M>
 __global__ __launch_bounds__(64) void backtrace_rc_kernel(const Lattice *__restrict__ lats, const int32_t *meta)
@@ -1163,9 +1207,9 @@ __global__ __launch_bounds__(64) void backtrace_rc_kernel(const Lattice *__restr
     const uint32_t halfB = B >> 1;
     const uint32_t dq = L / T, dr = L % T;
     const float NINF = ninf();
-    gcf32_t lp = (gcf32_t)d.lp;
-    const size_t ld = (size_t)d.ld;
-    const int col = lane < d.V ? lane : 0;
+    const char *lp = reinterpret_cast<const char *>(d.lp);
+    const size_t ldb = (size_t)d.ld * 4;                     // row pitch in bytes
+    const uint32_t col_off = (lane < d.V ? (uint32_t)lane : 0u) * 4u;
     gci32_t labx = (gci32_t)d.labx;
     const char *ck = reinterpret_cast<const char *>(d.bp);
     gi32_t path = (gi32_t)d.path;
@@ -1174,40 +1218,56 @@ __global__ __launch_bounds__(64) void backtrace_rc_kernel(const Lattice *__restr
 
     // floor(L*t/T) and remainder at the start of the last chunk; one chunk back = minus (32*L)/T, (32*L)%T
     uint32_t t0 = ((T - 1) / kCkFrames) * kCkFrames;
-    uint32_t q0, r0;
-    {
-        const uint64_t prod = (uint64_t)L * t0;
-        q0 = (uint32_t)(prod / T);
-        r0 = (uint32_t)(prod % T);
-    }
-    const uint32_t D32 = (uint32_t)(((uint64_t)L * kCkFrames) / T), R32 = (uint32_t)(((uint64_t)L * kCkFrames) % T);
+    // (64-bit divisions run on the vector unit: tell the compiler the results are wave-uniform)
+    const auto uni = [](uint64_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v); };
+    uint32_t q0 = uni(((uint64_t)L * t0) / T), r0 = uni(((uint64_t)L * t0) % T);
+    const uint32_t D32 = uni(((uint64_t)L * kCkFrames) / T), R32 = uni(((uint64_t)L * kCkFrames) % T);
 
     for (;;) {
         const int n = (int)(T - t0 < (uint32_t)kCkFrames ? T - t0 : (uint32_t)kCkFrames);
-        const int wlo = (p > 96 ? p - 96 : 0) & ~1;
+        const int wlo = __builtin_amdgcn_readfirstlane((p > 96 ? p - 96 : 0) & ~1);
         const int pb = wlo + 2 * lane;                       // this lane's blank position; its label position is pb+1
-        const int lab4 = labx[(size_t)(wlo >> 1) + lane];    // 4 * label of position pb+1 (zero padded past S)
-        const float veto = lab4 == 0 ? NINF : __builtin_inff();
-        float rows[kCkFrames];
-#pragma unroll
-        for (int f = 0; f < kCkFrames; ++f) {
-            const uint32_t tt = t0 + f < T ? t0 + f : T - 1;
-            rows[f] = lp[(size_t)tt * ld + col];
+        // All loads of the chunk are issued here, from inline asm (uniform base + lane offset, and invisible
+        // to hipcc, which would otherwise drain them all at the first use): labels, checkpoint, 32 rows.
+        // Each is released by a counted wait: at least the loads issued after it are still behind it.
+        int lab4;                                            // 4 * label of position pb+1 (zero padded past S)
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(lab4) : "v"((uint32_t)lane * 4u), "s"(labx + (wlo >> 1)) : "memory");
+        f32x2 ckv = {NINF, NINF};                            // scores of (pb, pb+1) after frame t0-1
+        if (t0 != 0) {
+            const uint32_t off = (uint32_t)((pb >> 4) & 63) * 64u + (uint32_t)(pb & 15) * 4u;
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(ckv) : "v"(off), "s"(ck + ((size_t)(t0 / kCkFrames) - 1) * 4096) : "memory");
         }
+        float rows[kCkFrames];                               // (frames past T-1, last chunk only, repeat row T-1: never walked)
+        {
+            const char *rp = lp + (size_t)t0 * ldb;
+            if (n == kCkFrames) {
+#pragma unroll
+                for (int f = 0; f < kCkFrames; ++f) {
+                    rows[f] = row_load(col_off, rp);
+                    rp += ldb;
+                }
+            } else {
+#pragma unroll
+                for (int f = 0; f < kCkFrames; ++f) {
+                    rows[f] = row_load(col_off, rp);
+                    rp += (f + 1 < n) ? ldb : 0;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(lab4), "+v"(ckv) : "i"(kCkFrames) : "memory");
+        const float veto = lab4 == 0 ? NINF : __builtin_inff();
         // scores after frame t0-1, limited to that frame's band
         float sb, sl;
         if (t0 == 0) {
             sb = pb == 0 ? 0.0f : NINF;   // virtual state before frame 0 (align.py:57-58)
             sl = NINF;
         } else {
-            const char *c = ck + ((size_t)(t0 / kCkFrames) - 1) * 4096 + (size_t)((pb >> 4) & 63) * 64 + (size_t)(pb & 15) * 4;
-            const float v0 = *(gcf32_t)c, v1 = *(gcf32_t)(c + 4);
             const uint32_t qm = r0 >= dr ? q0 - dq : q0 - dq - 1;
             const int32_t dl = (int32_t)qm - (int32_t)halfB;
             const uint32_t lo1 = (uint32_t)(dl > 0 ? dl : 0);
             const uint32_t hi1 = (L - lo1 < B) ? L : lo1 + B;
-            sb = ((uint32_t)pb >= lo1 && (uint32_t)pb < hi1) ? v0 : NINF;
-            sl = ((uint32_t)pb + 1 >= lo1 && (uint32_t)pb + 1 < hi1) ? v1 : NINF;
+            sb = ((uint32_t)pb >= lo1 && (uint32_t)pb < hi1 && lane < kRcLanes) ? ckv.x : NINF;
+            sl = ((uint32_t)pb + 1 >= lo1 && (uint32_t)pb + 1 < hi1 && lane < kRcLanes) ? ckv.y : NINF;
         }
         // ---- forward over the chunk: scores + back-pointer codes of the window ----
         uint32_t codes[kCkFrames / 8];
@@ -1220,17 +1280,24 @@ __global__ __launch_bounds__(64) void backtrace_rc_kernel(const Lattice *__restr
                 const int32_t dl = (int32_t)q - (int32_t)halfB;
                 const int32_t lo = dl > 0 ? dl : 0;
                 const int32_t hi = (L - (uint32_t)lo < B) ? (int32_t)L : lo + (int32_t)B;
-                const int32_t x = lo - wlo, y = hi - wlo;
-                // blank wlo+2l in [lo,hi) <=> l in [ceil(x/2), ceil(y/2));  label wlo+2l+1 <=> l in [ceil((x-1)/2), ceil((y-1)/2))
-                const auto half_up = [](int32_t v) { v = v > 0 ? v : 0; v = (v + 1) >> 1; return (uint32_t)(v < 64 ? v : 64); };
-                mask_b = lane_range(half_up(x), half_up(y));
-                mask_l = lane_range(half_up(x - 1), half_up(y - 1));
+                // window-relative band [x, y), clamped to the 2*kRcLanes cells that are computed.
+                // blank wlo+2l in band <=> l in [ceil(x/2), ceil(y/2));  label wlo+2l+1 <=> l in [floor(x/2), floor(y/2))
+                int32_t x = lo - wlo, y = hi - wlo;
+                x = x < 0 ? 0 : x;
+                y = y < 0 ? 0 : y;
+                asm("" : "+s"(x), "+s"(y));   // (keeps the clamp on the scalar unit: no v_med3)
+                x = x > 2 * kRcLanes ? 2 * kRcLanes : x;
+                y = y > 2 * kRcLanes ? 2 * kRcLanes : y;
+                const uint32_t xb = (uint32_t)(x + 1) >> 1, yb = (uint32_t)(y + 1) >> 1, xl = (uint32_t)x >> 1, yl = (uint32_t)y >> 1;
+                mask_b = lane_field(yb - xb, xb);
+                mask_l = lane_field(yl - xl, xl);
             }
+            row_wait_n(rows[f], kCkFrames - 1 - f);
             const float el = bperm(lab4, rows[f]);
             const float e0 = first_lane(rows[f]);
-            const float L1 = wave_shr1(sl, NINF);    // score of pb-1
-            const float B1 = wave_shr1(sb, NINF);    // score of pb-2
-            const float L2 = wave_shr1(L1, NINF);    // score of pb-3
+            const float L1 = wave_ror1(sl);    // score of pb-1 (lane 0: lane 63's, always -inf)
+            const float B1 = wave_ror1(sb);    // score of pb-2
+            const float L2 = wave_ror1(L1);    // score of pb-3 (lanes 0, 1: lanes 62, 63's, always -inf)
             uint32_t &word = codes[f >> 3];
             if ((f & 7) == 0) word = 0;
             float mb, ml;
@@ -1244,30 +1311,28 @@ __global__ __launch_bounds__(64) void backtrace_rc_kernel(const Lattice *__restr
             band_moved = dq != 0;
             if (rem >= T) { rem -= T; ++q; band_moved = true; }
         }
-        // ---- walk back over the chunk ----
+        // ---- walk back over the chunk: pathv[lane f] = position of frame t0+f, relative to wlo ----
 #pragma unroll
         for (int g = 0; g < kCkFrames / 8; ++g) codes[g] = rc_blank_to_uniform(codes[g]);
-        int pathv = 0, labv = 0;
-        float scv = 0.0f;
+        int pathv = 0;
         int qq = p - wlo;
 #pragma unroll
         for (int f = kCkFrames - 1; f >= 0; --f) {
             if (f < n) {
-                const int ln = qq >> 1;
-                const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)codes[f >> 3], ln) >> (4 * (7 - (f & 7)));
-                const int l4 = (qq & 1) ? __builtin_amdgcn_readlane(lab4, ln) : 0;
-                const uint32_t code = (qq & 1) ? w : (w >> 2);
-                const float sv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rows[f]), l4 >> 2));
+                const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)codes[f >> 3], qq >> 1) >> (4 * (7 - (f & 7)));
                 asm("v_writelane_b32 %0, %1, %2" : "+v"(pathv) : "s"(qq), "i"(f));
-                asm("v_writelane_b32 %0, %1, %2" : "+v"(labv) : "s"(l4 >> 2), "i"(f));
-                asm("v_writelane_b32 %0, %1, %2" : "+v"(scv) : "s"(sv), "i"(f));
-                qq -= bp_decode(code);
+                qq -= bp_decode((qq & 1) ? w : (w >> 2));
             }
         }
+        // best_path, best_labels = lab'[best_path], best_scores[t] = lp[t, best_labels[t]] (align.py:105-107):
+        // lane f does frame t0+f; the label and the score are gathers from lines this wave has just read
         if (lane < n) {
-            path[t0 + lane] = pathv + wlo;
-            lab_out[t0 + lane] = labv;
-            sc_out[t0 + lane] = scv;
+            const int pos = pathv + wlo;
+            const int lab = (pos & 1) ? (labx[pos >> 1] >> 2) : 0;
+            const float sv = *(gcf32_t)(lp + (size_t)(t0 + lane) * ldb + (size_t)lab * 4);
+            path[t0 + lane] = pos;
+            lab_out[t0 + lane] = lab;
+            sc_out[t0 + lane] = sv;
         }
         p = qq + wlo;
         if (t0 == 0) break;
