@@ -555,6 +555,7 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
     const uint32_t *bp = reinterpret_cast<const uint32_t *>(d.bp);   // wave-uniform row base
     const uint32_t lane_store_off = (uint32_t)lane * 16u;   // back-pointers: [t/4][block][t%4] dwords
 
+    const char *row_ahead = lp + (size_t)(D < T ? D : T - 1) * ld;   // row min(t+D, T-1) of the current frame t
     for (uint32_t tb = 0; tb < T; tb += D) {
         // back-pointer words of the 4 frames of this group.  Frames past T leave theirs undefined (the
         // buffer is padded to whole groups); an empty asm output costs nothing, a zero costs a v_mov.
@@ -565,29 +566,34 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
         for (int dd = 0; dd < D; ++dd) {
             const uint32_t t = tb + dd;
             if (t < T) {
-                // A. band of frame t+1; re-label the lanes whose block has been passed by lo
+                // A. band of frame t+1; re-label the lanes whose block has been passed by lo.  The band is a
+                // function of floor(L*t/T): nothing to do in the frames where that does not move (every
+                // instruction costs issue time here, scalar ones included)
                 uint32_t nq = q + dq, nrem = rem + dr;
                 if (nrem >= T) { nrem -= T; ++nq; }
-                const int32_t dlo = (int32_t)nq - (int32_t)halfB;  // signed on purpose: s_max_i32, not a VALU usubsat
-                uint32_t nlo = (uint32_t)(dlo > 0 ? dlo : 0);
-                uint32_t nhi = (L - nlo < B) ? L : nlo + B;
-                if (t + 1 == T) { nlo = lo; nhi = hi; }  // no frame T: keep the last band and labels
+                uint32_t nlo = lo, nhi = hi;
                 bool relabeled = false;
                 bool relabel_lane = false;
-                if ((nlo >> 4) != blo) {
-                    blo = nlo >> 4;
-                    const int nb = (int)blo + ((lane - (int)blo) & 63);
-                    if (nb != blk) {
-                        blk = nb;
-                        load_block_labels(labx, blk, la);
-                        relabel_lane = true;
-                        // consume the loads HERE: otherwise the wait for them lands at the merge
-                        // point as an every-frame s_waitcnt vmcnt(0) that also drains the row
-                        // prefetches and the back-pointer stores
+                const bool moved = nq != q && t + 1 != T;   // no frame T: keep the last band and labels
+                if (moved) {
+                    const int32_t dlo = (int32_t)nq - (int32_t)halfB;  // signed on purpose: s_max_i32, not a VALU usubsat
+                    nlo = (uint32_t)(dlo > 0 ? dlo : 0);
+                    nhi = (L - nlo < B) ? L : nlo + B;
+                    if ((nlo >> 4) != blo) {
+                        blo = nlo >> 4;
+                        const int nb = (int)blo + ((lane - (int)blo) & 63);
+                        if (nb != blk) {
+                            blk = nb;
+                            load_block_labels(labx, blk, la);
+                            relabel_lane = true;
+                            // consume the loads HERE: otherwise the wait for them lands at the merge
+                            // point as an every-frame s_waitcnt vmcnt(0) that also drains the row
+                            // prefetches and the back-pointer stores
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(la[i]));
+                            for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(la[i]));
+                        }
+                        relabeled = true;
                     }
-                    relabeled = true;
                 }
                 // B. row t+1 (its emissions are gathered while frame t is computed).  It was issued D-1
                 // frames ago; since then (D-2) frames each issued one row load, and the group store that
@@ -617,13 +623,11 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                 gw[dd] = word;
                 // live <=> in band and (moved in from a live state, or stayed on a live state)
                 if constexpr (!LITE) pres2 = live_pairs(pres2, word, band2);
-                // prefetch the row of frame t+D
-                {
-                    const uint32_t tt = t + D < T ? t + D : T - 1;
-                    rows[dd] = row_load(lane_off, lp + (size_t)tt * ld);
-                }
+                // prefetch the row of frame t+D (the last row again once there is none: never consumed)
+                rows[dd] = row_load(lane_off, row_ahead);
+                row_ahead += t + D + 1 < T ? ld : 0;
                 // D. lane masks of frame t+1
-                if (nlo != lo || nhi != hi) {
+                if (moved && (nlo != lo || nhi != hi)) {
                     if (nhi - hi <= 1u && nlo - lo <= 1u) {
                         if (nhi != hi) band_toggle(mk, hi);
                         if (nlo != lo) band_toggle(mk, lo);
