@@ -556,6 +556,8 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
     const uint32_t lane_store_off = (uint32_t)lane * 16u;   // back-pointers: [t/4][block][t%4] dwords
 
     const char *row_ahead = lp + (size_t)(D < T ? D : T - 1) * ld;   // row min(t+D, T-1) of the current frame t
+    uint32_t step_thr = dq != 0 ? 0u : T;   // floor(L*t/T) moves in this frame <=> rem + dr >= step_thr
+    asm("" : "+s"(step_thr));               // (opaque: one s_cmp + s_cbranch per frame instead of a boolean expression)
     for (uint32_t tb = 0; tb < T; tb += D) {
         // back-pointer words of the 4 frames of this group.  Frames past T leave theirs undefined (the
         // buffer is padded to whole groups); an empty asm output costs nothing, a zero costs a v_mov.
@@ -569,30 +571,35 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                 // A. band of frame t+1; re-label the lanes whose block has been passed by lo.  The band is a
                 // function of floor(L*t/T): nothing to do in the frames where that does not move (every
                 // instruction costs issue time here, scalar ones included)
-                uint32_t nq = q + dq, nrem = rem + dr;
-                if (nrem >= T) { nrem -= T; ++nq; }
                 uint32_t nlo = lo, nhi = hi;
                 bool relabeled = false;
                 bool relabel_lane = false;
-                const bool moved = nq != q && t + 1 != T;   // no frame T: keep the last band and labels
-                if (moved) {
-                    const int32_t dlo = (int32_t)nq - (int32_t)halfB;  // signed on purpose: s_max_i32, not a VALU usubsat
-                    nlo = (uint32_t)(dlo > 0 ? dlo : 0);
-                    nhi = (L - nlo < B) ? L : nlo + B;
-                    if ((nlo >> 4) != blo) {
-                        blo = nlo >> 4;
-                        const int nb = (int)blo + ((lane - (int)blo) & 63);
-                        if (nb != blk) {
-                            blk = nb;
-                            load_block_labels(labx, blk, la);
-                            relabel_lane = true;
-                            // consume the loads HERE: otherwise the wait for them lands at the merge
-                            // point as an every-frame s_waitcnt vmcnt(0) that also drains the row
-                            // prefetches and the back-pointer stores
+                bool moved = false;
+                rem += dr;
+                if (__builtin_expect(rem >= step_thr, 0)) {
+                    asm volatile("" ::: "memory");  // a real branch: the common frame pays an add, a compare and a jump
+                    q += dq;
+                    if (rem >= T) { rem -= T; ++q; }
+                    if (t + 1 != T) {   // no frame T: keep the last band and labels
+                        moved = true;
+                        const int32_t dlo = (int32_t)q - (int32_t)halfB;  // signed on purpose: s_max_i32, not a VALU usubsat
+                        nlo = (uint32_t)(dlo > 0 ? dlo : 0);
+                        nhi = (L - nlo < B) ? L : nlo + B;
+                        if ((nlo >> 4) != blo) {
+                            blo = nlo >> 4;
+                            const int nb = (int)blo + ((lane - (int)blo) & 63);
+                            if (nb != blk) {
+                                blk = nb;
+                                load_block_labels(labx, blk, la);
+                                relabel_lane = true;
+                                // consume the loads HERE: otherwise the wait for them lands at the merge
+                                // point as an every-frame s_waitcnt vmcnt(0) that also drains the row
+                                // prefetches and the back-pointer stores
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(la[i]));
+                                for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(la[i]));
+                            }
+                            relabeled = true;
                         }
-                        relabeled = true;
                     }
                 }
                 // B. row t+1 (its emissions are gathered while frame t is computed).  It was issued D-1
@@ -642,8 +649,6 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                         for (int i = 0; i < 8; ++i) vz[i] = la[i] == 0 ? NINF : __builtin_inff();
                     }
                 }
-                q = nq;
-                rem = nrem;
                 pend_reset = relabeled;
                 reset_lane = relabel_lane;
             }
