@@ -5,7 +5,7 @@
 
 Workload (BASELINE.json configs[1]): synthetic log-probs T=50000 x V=64, S=5000 phonemes
 (L=10001), beam_size=1000, max_move=4.  One "step" = one pass of the hot path (label prep +
-forward DP + backtrace + output gathers) over a batch of B independent lattices of that
+forward DP + back-pointer recomputation and backtrace + outputs) over a batch of B independent lattices of that
 shape, each with its own hash-generated inputs, already resident in HBM.  Metric = aligned
 audio frames per second, whole job (all ranks).  N>1: one process per GPU (launched by
 torch.distributed.run), lattices sharded across ranks, no data-path collective (weak scaling).
@@ -25,18 +25,28 @@ T, V, S, BEAM, MAX_MOVE = 50000, 64, 5000, 1000, 4
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+CK_FRAMES = 32   # kokoro-align_amd/csrc/ka_kernels.hpp kCkFrames: frames between stored score rings
+
+
 def algorithmic_bytes_per_frame():
-    """4V (log-prob row read once) + Wbar/4 (2-bit back-pointer per band cell,
-    written once) for the forward DP kernel; + 0.25 (back-pointer read) + 12 (three 4-byte
-    outputs) for the backtrace.  Wbar from the band definition (align.py:64-65)."""
+    """HBM bytes per frame that the algorithm has to move.
+
+    Dominant kernel (forward_ck_kernel, scores only): the log-prob row read once (4V) + the score ring
+    (1024 slots x 4 B) written once every CK_FRAMES frames.  Whole job: + the second kernel
+    (backtrace_rc_kernel): the row once more (4V), the 128-cell window of a checkpoint and of the labels per
+    chunk, and the three 4-byte outputs.
+    For reference, SURVEY.md §8d's figure for the store-every-back-pointer formulation
+    (KA_MODE_WAVE_EXACT): 4V + Wbar/4 forward, + 0.25 + 12 backtrace, Wbar from align.py:64-65."""
     L = 2 * S + 1
     cells = 0
     for t in range(T):
         lo = max(0, L * t // T - BEAM // 2)
         cells += min(lo + BEAM, L) - lo
     wbar = cells / T
-    fwd = 4.0 * V + wbar / 4.0
-    return fwd, fwd + 12.25, wbar
+    fwd = 4.0 * V + 4096.0 / CK_FRAMES
+    job = fwd + 4.0 * V + (512.0 + 256.0) / CK_FRAMES + 12.0
+    survey_fwd = 4.0 * V + wbar / 4.0
+    return fwd, job, wbar, survey_fwd
 
 
 def cpu_baseline(min_seconds):
@@ -182,7 +192,7 @@ def main():
     if rank == 0:
         frames_per_step = B * T * world
         value = frames_per_step * args.steps / elapsed
-        fwd_b, job_b, wbar = algorithmic_bytes_per_frame()
+        fwd_b, job_b, wbar, survey_fwd_b = algorithmic_bytes_per_frame()
         fwd_s = float(np.mean(fwd_ms)) * 1e-3
         achieved = B * T * fwd_b / fwd_s / 1e9
         # HBM bytes of one forward launch cannot be counted from inside this process: they come from the
@@ -208,8 +218,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same batch size)" if traffic else None,
-                         "kernel": "forward_w16_kernel<4,false>", "kernel_ms": fwd_s * 1e3,
-                         "algorithmic_bytes_per_frame": fwd_b, "mean_band_width": wbar},
+                         "kernel": "forward_ck_kernel<4,false>", "kernel_ms": fwd_s * 1e3,
+                         "algorithmic_bytes_per_frame": fwd_b, "mean_band_width": wbar,
+                         "survey_8d_bytes_per_frame": survey_fwd_b,
+                         "achieved_with_survey_8d_bytes": B * T * survey_fwd_b / fwd_s / 1e9},
             "kernels_ms": {"prep": float(np.mean(prep_ms)), "forward": float(np.mean(fwd_ms)),
                            "backtrace": float(np.mean(bt_ms)), "gather": float(np.mean(ga_ms))},
             "job_bytes_per_frame": job_b,

@@ -58,10 +58,10 @@ rows = []
 for (k, g), c in sorted(pmc.items()):
     rows.append({"kernel": k, "grid_threads": g, "counters_per_dispatch": {n: sum(v) / len(v) for n, v in c.items()}})
 summary["pmc"] = rows
-# HBM traffic of the forward kernel's batch launch: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950
+# HBM traffic of the dominant (forward) kernel's batch launch: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950
 # FETCH_SIZE reports half of a coalesced streaming read (MI355X_MICROARCH.md §HBM) -> x2.
 for r in rows:
-    if "forward_w16" in r["kernel"] and "false" in r["kernel"] and r["grid_threads"] == lattices * 64:
+    if "forward_ck" in r["kernel"] and "false" in r["kernel"] and r["grid_threads"] == lattices * 64:
         c = r["counters_per_dispatch"]
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             read_b = c["FETCH_SIZE"] * 1024 * 2
@@ -69,7 +69,7 @@ for r in rows:
             summary["forward_hbm_bytes_per_launch"] = {"read_corrected_x2": read_b, "write": write_b, "total": read_b + write_b}
             with open(os.path.join(out_dir, "pmc_traffic.json"), "wt") as f:
                 json.dump({"lattices": lattices, "hbm_bytes_per_launch": read_b + write_b, "tag": tag,
-                           "note": "FETCH_SIZE*1024*2 + WRITE_SIZE*1024 of forward_w16_kernel<4,false>, one launch"}, f)
+                           "note": "FETCH_SIZE*1024*2 + WRITE_SIZE*1024 of forward_ck_kernel<4,false>, one launch"}, f)
 bj = os.path.join(src, "bench_under_rocprof.json")
 if os.path.exists(bj):
     try:
