@@ -1334,14 +1334,23 @@ __global__ __launch_bounds__(64) void backtrace_rc_kernel(const Lattice *__restr
             }
         }
         // best_path, best_labels = lab'[best_path], best_scores[t] = lp[t, best_labels[t]] (align.py:105-107):
-        // lane f does frame t0+f; the label and the score are gathers from lines this wave has just read
-        if (lane < n) {
+        // lane f does frame t0+f.  The score comes from the row registers (lane v of rows[f] = lp[t0+f, v]): a
+        // gather from memory would fetch a 128-byte line per frame again (measured: +57 GB per batch, and
+        // this kernel runs at HBM speed).  Frame f: every lane looks up its own column in row f, lane f keeps it.
+        {
             const int pos = pathv + wlo;
-            const int lab = (pos & 1) ? (labx[pos >> 1] >> 2) : 0;
-            const float sv = *(gcf32_t)(lp + (size_t)(t0 + lane) * ldb + (size_t)lab * 4);
-            path[t0 + lane] = pos;
-            lab_out[t0 + lane] = lab;
-            sc_out[t0 + lane] = sv;
+            const int l4 = (lane < n && (pos & 1)) ? labx[pos >> 1] : 0;   // 4 * label = byte address of the column
+            float sv = 0.0f;
+#pragma unroll
+            for (int f = 0; f < kCkFrames; ++f) {
+                const int got = __builtin_amdgcn_readlane(__builtin_bit_cast(int, bperm(l4, rows[f])), f);
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(sv) : "s"(got), "i"(f));
+            }
+            if (lane < n) {
+                path[t0 + lane] = pos;
+                lab_out[t0 + lane] = l4 >> 2;
+                sc_out[t0 + lane] = sv;
+            }
         }
         p = qq + wlo;
         if (t0 == 0) break;
