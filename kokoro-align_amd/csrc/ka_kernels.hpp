@@ -8,22 +8,29 @@
 //                    j* = first j attaining the max; bp_t[p] = j*           (align.py:83-85)
 //   end = highest live position of frame T-1; walk bp back to frame 0       (align.py:99-102)
 //
-// Layout of the fast path ("w16": one 64-lane wavefront owns one lattice):
+// Layout of the fast path (one 64-lane wavefront owns one lattice):
 //   * 1024 slots = 64 lanes x 16 cells; position p lives in slot p mod 1024,
 //     lane (p>>4)&63, cell p&15.  The live band is at most 1009 wide, so the 64 blocks
 //     [lo>>4, (lo>>4)+63] never alias; as `lo` passes a block its lane is re-labelled
 //     for block+64.  No data ever moves when the band slides.
 //   * scores live in 16 VGPRs per lane; the three neighbours p-1..p-3 of a lane's first
-//     cells come from the previous lane with DPP wave_ror:1 (fused into v_add_f32_dpp).
+//     cells come from the previous lane with DPP wave_ror:1.
 //   * lane v of a "row" register holds lp[t, v] (V <= 64): one coalesced 256-B load per
 //     frame, prefetched 4 frames ahead; blank emission = readfirstlane, label emissions
-//     = 8 ds_bpermute per frame (no LDS memory, no bank conflicts), issued one frame ahead.
-//   * max-of-(3|4) as a tournament of v_cmp_gt_f32 -> SGPR lane masks; the 2 back-pointer
-//     bits are combined on the scalar unit and shifted into a per-lane 32-bit word with
-//     v_addc_co_u32 (word = 2*word + bit): 16 cells x 2 bit = one dword per lane per
-//     frame = one coalesced 256-B store per frame.
+//     = 8 ds_bpermute per frame (no LDS memory, no bank conflicts).
 //   * the band [lo,hi) is applied with 16 wave-uniform 64-bit lane masks (one per cell
 //     index) held in SGPRs and updated only when lo/hi move.
+// Three kernel forms:
+//   * checkpointed: forward_ck_kernel keeps scores only and stores the score ring every 32
+//     frames; backtrace_rc_kernel recomputes the back-pointers of the 124-cell window below the
+//     path, chunk by chunk, walks it and writes all outputs.  Time on gfx950 is proportional
+//     to the number of instructions executed: recomputing 3 % of the cells beats comparing and
+//     packing all of them.
+//   * exact: forward_w16_kernel finds the first move attaining the max with v_cmp_eq -> SGPR
+//     lane masks, combines them on the scalar unit and shifts the 2-bit code into a per-lane
+//     word with v_addc_co_u32 (16 cells x 2 bit = one dword per lane per frame);
+//     backtrace_w16_kernel walks the stored codes, gather_outputs_kernel fills labels/scores.
+//   * workgroup (forward_wg4_kernel): four wavefronts per lattice, for latency.
 // No MFMA: ~7 flop per cell, nothing to contract.
 #pragma once
 #include <hip/hip_runtime.h>
