@@ -366,3 +366,30 @@ def test_non_default_stream_and_two_engines(ka):
     [t.join() for t in ts]
     for name in (0, 1):
         assert all(np.array_equal(p, want[0]) for p in results[name]), name
+
+
+def test_checkpointed_form_hands_over_what_it_cannot_do(ka):
+    """The scores-only forward kernel is valid for finite log-probs of sane magnitude; lattices with -inf
+    entries or absurd magnitudes must come out identical through the exact kernels, in the same batch as
+    lattices that stay on the checkpointed path (they share one workspace region per lattice)."""
+    rng = np.random.default_rng(77)
+    lps, labs = [], []
+    for i in range(9):
+        T, V, S = 700 + 37 * i, 39, 150 + 11 * i
+        lp = np.log(rng.dirichlet(np.ones(V) * 0.3, size=T)).astype(np.float32)
+        if i % 3 == 1:
+            lp[rng.random((T, V)) < 0.05] = -np.inf          # a state can be live with score -inf
+        if i % 3 == 2:
+            lp[rng.integers(0, T), rng.integers(0, V)] = -3e31   # finite, but beyond the magnitude the check allows
+        lps.append(lp)
+        labs.append(rng.integers(1, V, size=S).astype(np.int32))
+    res, status, total = ka.ctc_best_path_batch(lps, labs, 1000, 4, return_status=True)
+    for i, (lp, lab) in enumerate(zip(lps, labs)):
+        try:
+            w = O.ctc_best_path_c(lp, lab, 1000, 4, return_total=True)
+        except ValueError:
+            assert status[i] == -1, i
+            continue
+        assert status[i] == 0, i
+        assert _same(res[i], w[:3]), i
+        assert np.float32(total[i]).view(np.int32) == np.float32(w[3]).view(np.int32), i
