@@ -23,10 +23,14 @@ for rep in range(3):
     nbad_end = int((ends != 2 * S).sum())
     bad = []
     wrong = np.nonzero(ends != 2 * S)[0][:4].tolist()
-    for i in sorted(set([0, 1, B - 1] + wrong)):
+    sample = np.random.default_rng(rep).integers(0, B, size=10).tolist()
+    for i in sorted(set([0, 1, B - 1] + wrong + sample)):
         want = O.ctc_best_path_c(O.hash_logprobs(T, V, i), O.hash_labels(S, V, i), 1000, 4)
         got = batch.path[i].cpu().numpy()
         if not np.array_equal(got, want[0]):
             j = int(np.argmax(got != want[0]))
             bad.append((i, j, int((got != want[0]).sum()), got[j:j+4].tolist(), want[0][j:j+4].tolist(), int(got[-1])))
+        elif not (np.array_equal(batch.best_labels[i].cpu().numpy(), want[1])
+                  and np.array_equal(batch.best_scores[i].cpu().numpy().view(np.int32), want[2].view(np.int32))):
+            bad.append((i, "labels/scores differ"))
     print(f"rep {rep} mode={mode} B={B} T={T}: ends wrong: {nbad_end} (idx {np.nonzero(ends != 2 * S)[0][:8].tolist()}); sample mismatches: {bad}")
