@@ -354,6 +354,8 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
         // few lattices: 4 wavefronts per lattice (per-frame latency); many: 1 wavefront per lattice (throughput)
         const bool wg = e->mode == KA_MODE_WORKGROUP || (e->mode == KA_MODE_AUTO && n_fast <= kAutoWorkgroupMaxLattices);
         form = wg ? kFormWorkgroup : (e->mode == KA_MODE_WAVE_EXACT ? kFormWaveExact : kFormWaveCheckpointed);
+        // backtrace_rc_kernel keeps 34*T in 32 bits (descriptors are sorted longest first)
+        if (form == kFormWaveCheckpointed && sh[order[0]].T >= (int64_t(1) << 26)) form = kFormWaveExact;
         switch (max_move) {
         case 1: launch_forward<1>(d_lats, n_fast, d_meta, stream, form); break;
         case 2: launch_forward<2>(d_lats, n_fast, d_meta, stream, form); break;

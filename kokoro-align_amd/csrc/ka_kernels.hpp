@@ -1285,12 +1285,18 @@ __global__ __launch_bounds__(64) void backtrace_rc_kernel(const Lattice *__restr
         }
         // ---- forward over the chunk: scores + back-pointer codes of the window ----
         uint32_t codes[kCkFrames / 8];
-        uint32_t q = q0, rem = r0;
+        // floor(L*(t0+f)/T) of all frames of the chunk at once, lane f <-> frame f (r0 + 33*dr < 34*T: the host
+        // keeps T below 2^26 in this form), and the frames after which it moves as a bit mask: the common frame
+        // then pays one s_bitcmp1 + s_cbranch for the band instead of a scalar Bresenham step
+        const uint32_t qnum = r0 + (uint32_t)lane * dr;
+        const uint32_t qa = q0 + (uint32_t)lane * dq + qnum / T;
+        const uint32_t qb = q0 + (uint32_t)(lane + 1) * dq + (qnum + dr) / T;
+        const uint32_t moves = (uint32_t)__builtin_amdgcn_ballot_w64(qa != qb);   // bit f: frame f+1's band differs from frame f's
         uint64_t mask_b = 0, mask_l = 0;
-        bool band_moved = true;
 #pragma unroll
         for (int f = 0; f < kCkFrames; ++f) {
-            if (band_moved) {
+            if (f == 0 || ((moves >> (f > 0 ? f - 1 : 0)) & 1u)) {
+                const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)qa, f);
                 const int32_t dl = (int32_t)q - (int32_t)halfB;
                 const int32_t lo = dl > 0 ? dl : 0;
                 const int32_t hi = (L - (uint32_t)lo < B) ? (int32_t)L : lo + (int32_t)B;
@@ -1319,11 +1325,6 @@ __global__ __launch_bounds__(64) void backtrace_rc_kernel(const Lattice *__restr
             cell_label<M, true>(sl, sb, L1, B1, el, veto, ml, word);
             sb = select_by_mask(NINF, mb, mask_b);
             sl = select_by_mask(NINF, ml, mask_l);
-            // band of the next frame
-            q += dq;
-            rem += dr;
-            band_moved = dq != 0;
-            if (rem >= T) { rem -= T; ++q; band_moved = true; }
         }
         // ---- walk back over the chunk: pathv[lane f] = position of frame t0+f, relative to wlo ----
 #pragma unroll
