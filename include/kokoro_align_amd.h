@@ -102,7 +102,8 @@ int ka_batch_finish(ka_engine *e, float *total_score, int32_t *status);
  *                       lattices): the forward kernel keeps scores only and stores the score ring every 32
  *                       frames; the backtrace kernel recomputes the back-pointers of the ~100 cells around the
  *                       path from those checkpoints and writes all three outputs.  Lattices whose log-probs are
- *                       not all finite are redone by the exact kernels in the same call.
+ *                       not all finite are redone by the exact kernels in the same call; a call with a lattice of
+ *                       2^26 frames or more runs entirely in the exact form.
  *   KA_MODE_WAVE_EXACT  one wavefront per lattice, every back-pointer stored (2 bits per band cell).
  *   KA_MODE_WORKGROUP   four wavefronts per lattice with an LDS hand-off per frame (latency: a single file, a
  *                       book's few dozen chapters); back-pointers stored.
