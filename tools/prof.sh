@@ -3,7 +3,7 @@
 set -e
 B=${1:-2048}; TAG=${2:-r01}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_$TAG
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --lattices $B --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex 'forward_ck|backtrace_rc|forward_w16|backtrace_w16|gather_outputs' --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --lattices $B --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $OUT/pmc_fetch.err
