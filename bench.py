@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--lattices", type=int, default=int(os.environ.get("KA_BENCH_LATTICES", "8192")),
                     help="lattices per GPU per step")
+    ap.add_argument("--mode", default="auto", choices=["auto", "wave", "wave_exact", "workgroup"],
+                    help="kernel form of the batch run (DESIGN.md section 4); auto = wave (checkpointed) at this batch size")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -144,6 +146,7 @@ def main():
     assert lib.ka_hash_labels_batch_i32(labs.data_ptr(), B, S, V, S, seed0, stream) == 0
     torch.cuda.synchronize()
     batch.engine.set_profiling(True)
+    batch.engine.set_mode(args.mode)
 
     def barrier():
         torch.cuda.synchronize()
@@ -179,6 +182,7 @@ def main():
     # single-lattice latency (the serial T-chain; one wavefront busy on the whole chip)
     single = None
     if rank == 0:
+        batch.engine.set_mode("auto")
         one = DeviceBatch([lps[0]], [labs[0]], BEAM, MAX_MOVE)   # 1 lattice: KA_MODE_AUTO picks the 4-wavefront form
         one.engine.set_profiling(True)
         one.run()
@@ -194,6 +198,10 @@ def main():
         value = frames_per_step * args.steps / elapsed
         fwd_b, job_b, wbar, survey_fwd_b = algorithmic_bytes_per_frame()
         fwd_s = float(np.mean(fwd_ms)) * 1e-3
+        checkpointed = args.mode in ("auto", "wave") and B > 1024   # the form KA_MODE_AUTO takes at this batch size
+        if not checkpointed:     # every back-pointer stored: SURVEY.md 8d's bytes are this form's own
+            fwd_b = survey_fwd_b
+            job_b = survey_fwd_b + 12.25 + 4.0 * V / 2
         achieved = B * T * fwd_b / fwd_s / 1e9
         # HBM bytes of one forward launch cannot be counted from inside this process: they come from the
         # committed rocprofv3 PMC run (tools/prof.sh -> tools/summarize_profile.py) at the same batch size
@@ -203,7 +211,7 @@ def main():
             try:
                 with open(tf) as f:
                     pt = json.load(f)
-                if int(pt.get("lattices", -1)) == B:
+                if int(pt.get("lattices", -1)) == B and checkpointed:
                     traffic = pt.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -214,11 +222,15 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (hash-generated log-probs and labels, in HBM)",
             "config": {"workload": f"cfg2: T={T} x V={V} log-probs, S={S} phonemes (L={2 * S + 1}), beam_size={BEAM}, "
                                    f"max_move={MAX_MOVE}; batch of {B} independent lattices per GPU per step",
-                       "lattices_per_gpu": B, "frames_per_step": frames_per_step, "parallelism": f"lattice-sharded x{world}"},
+                       "lattices_per_gpu": B, "frames_per_step": frames_per_step, "parallelism": f"lattice-sharded x{world}",
+                       "kernel_form": args.mode},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same batch size)" if traffic else None,
-                         "kernel": "forward_ck_kernel<4,false>", "kernel_ms": fwd_s * 1e3,
+                         "kernel": "forward_ck_kernel<4,false>" if checkpointed else
+                                   ("forward_w16_kernel<4,false>" if args.mode == "wave_exact" or (args.mode == "wave" and B <= 1024)
+                                    else "forward_wg4_kernel<4,false>"),
+                         "kernel_ms": fwd_s * 1e3,
                          "algorithmic_bytes_per_frame": fwd_b, "mean_band_width": wbar,
                          "survey_8d_bytes_per_frame": survey_fwd_b,
                          "achieved_with_survey_8d_bytes": B * T * survey_fwd_b / fwd_s / 1e9},
