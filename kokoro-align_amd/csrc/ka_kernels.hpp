@@ -119,8 +119,6 @@ __device__ __forceinline__ float wave_ror1(float x)
     // destination needs no initial value: mov_dpp instead of update_dpp(0, ..) saves a v_mov per call
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x13C, 0xF, 0xF, false));
 }
-// 64-bit lane mask of (a > b), ordered compare
-__device__ __forceinline__ uint64_t fgt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 2 /*FCMP_OGT*/); }
 // w = 2*w + mask[lane]
 __device__ __forceinline__ uint32_t shl1_in(uint32_t w, uint64_t mask)
 {
