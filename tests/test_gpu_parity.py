@@ -393,3 +393,36 @@ def test_checkpointed_form_hands_over_what_it_cannot_do(ka):
         assert status[i] == 0, i
         assert _same(res[i], w[:3]), i
         assert np.float32(total[i]).view(np.int32) == np.float32(w[3]).view(np.int32), i
+
+
+@pytest.mark.parametrize("mm", [1, 2, 3, 4])
+def test_random_small_shapes_and_narrow_beams(ka, mm):
+    """Many small lattices with odd shapes: T not a multiple of the checkpoint interval, beams narrower than the
+    recompute window (its cells straddle both band edges), L >> T and L << T, S = 0, V = 1."""
+    rng = np.random.default_rng(900 + mm)
+    groups = {}
+    for i in range(160):
+        V = int(rng.choice([1, 2, 5, 64]))
+        beam = int(rng.choice([1, 2, 5, 16, 64, 1000]))
+        S = int(rng.integers(0, 150))
+        T = int(rng.integers(1, 400))
+        lp = (rng.standard_normal((T, V)) * 3).astype(np.float32)
+        if i % 5 == 0:
+            lp = np.round(lp)                                  # exact ties
+        labels = rng.integers(0 if (V > 1 and i % 4 == 0) or V == 1 else 1, V, size=S).astype(np.int32)
+        groups.setdefault((V, beam), []).append((lp, labels))
+    n_ok = 0
+    for (V, beam), cases in groups.items():
+        res, status, total = ka.ctc_best_path_batch([c[0] for c in cases], [c[1] for c in cases], beam, mm,
+                                                    return_status=True)
+        for j, (lp, labels) in enumerate(cases):
+            try:
+                w = O.ctc_best_path_c(lp, labels, beam, mm, return_total=True)
+            except ValueError:
+                assert status[j] == -1, (V, beam, j, lp.shape, labels.shape)
+                continue
+            assert status[j] == 0, (V, beam, j, lp.shape, labels.shape)
+            assert _same(res[j], w[:3]), (V, beam, j, lp.shape, labels.shape)
+            assert np.float32(total[j]).view(np.int32) == np.float32(w[3]).view(np.int32)
+            n_ok += 1
+    assert n_ok > 20
