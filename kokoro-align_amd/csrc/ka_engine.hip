@@ -141,6 +141,13 @@ void launch_forward(const ka::Lattice *d_lats, int n, int32_t *d_meta, hipStream
     hipLaunchKernelGGL((ka::forward_w16_kernel<M, true>), dim3(n), dim3(64), 0, s, d_lats, d_meta, only_flagged);
 }
 
+template <int M>
+void launch_backtrace_rc(const ka::Lattice *d_lats, int n, int32_t *d_meta, hipStream_t s)
+{
+    hipLaunchKernelGGL((ka::backtrace_rc_kernel<M, false>), dim3(n), dim3(64), 0, s, d_lats, d_meta);
+    hipLaunchKernelGGL((ka::backtrace_rc_kernel<M, true>), dim3(n), dim3(64), 0, s, d_lats, d_meta);
+}
+
 }  // namespace
 
 extern "C" {
@@ -370,10 +377,10 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
     if (n_fast > 0) {
         if (form == kFormWaveCheckpointed) {
             switch (max_move) {
-            case 1: hipLaunchKernelGGL(ka::backtrace_rc_kernel<1>, dim3(n_fast), dim3(64), 0, stream, d_lats, d_meta); break;
-            case 2: hipLaunchKernelGGL(ka::backtrace_rc_kernel<2>, dim3(n_fast), dim3(64), 0, stream, d_lats, d_meta); break;
-            case 3: hipLaunchKernelGGL(ka::backtrace_rc_kernel<3>, dim3(n_fast), dim3(64), 0, stream, d_lats, d_meta); break;
-            default: hipLaunchKernelGGL(ka::backtrace_rc_kernel<4>, dim3(n_fast), dim3(64), 0, stream, d_lats, d_meta); break;
+            case 1: launch_backtrace_rc<1>(d_lats, n_fast, d_meta, stream); break;
+            case 2: launch_backtrace_rc<2>(d_lats, n_fast, d_meta, stream); break;
+            case 3: launch_backtrace_rc<3>(d_lats, n_fast, d_meta, stream); break;
+            default: launch_backtrace_rc<4>(d_lats, n_fast, d_meta, stream); break;
             }
         }
         hipLaunchKernelGGL(ka::backtrace_w16_kernel, dim3(n_fast), dim3(64), 0, stream, d_lats, d_meta, only_flagged);

@@ -1204,13 +1204,15 @@ __device__ __forceinline__ uint64_t lane_field(uint32_t count, uint32_t first)
 constexpr int kRcLanes = 62;   // lanes 62 and 63 are kept at -inf: they are the "nothing below position 0" that
                                // wave_ror hands to lanes 0 and 1 (window width 124 >= 97 + slack)
 
-template <int M>
+template <int M, bool ZL>
 __global__ __launch_bounds__(64) void backtrace_rc_kernel(const Lattice *__restrict__ lats, const int32_t *meta)
 {
     const Lattice &d = lats[blockIdx.x];
     const int lane = threadIdx.x;
     const int32_t *mt = meta + 4 * (size_t)d.idx;
-    if (__builtin_amdgcn_readfirstlane(mt[2]) & kFlagExact) return;   // handled by the exact kernels
+    const int flags = __builtin_amdgcn_readfirstlane(mt[2]);
+    if (flags & kFlagExact) return;                          // handled by the exact kernels
+    if (((flags & kFlagZeroLabel) != 0) != ZL) return;       // the other instance's lattice (as in the forward kernels)
     int p = __builtin_amdgcn_readfirstlane(mt[1]);
     if (p < 0) return;  // empty beam: status already set by the forward kernel
     const uint32_t T = (uint32_t)__builtin_amdgcn_readfirstlane(d.T);
@@ -1320,7 +1322,7 @@ __global__ __launch_bounds__(64) void backtrace_rc_kernel(const Lattice *__restr
             if ((f & 7) == 0) word = 0;
             float mb, ml;
             cell_blank<M>(sb, L1, L2, e0, mb, word);
-            cell_label<M, true>(sl, sb, L1, B1, el, veto, ml, word);
+            cell_label<M, ZL>(sl, sb, L1, B1, el, veto, ml, word);
             sb = select_by_mask(NINF, mb, mask_b);
             sl = select_by_mask(NINF, ml, mask_l);
         }
