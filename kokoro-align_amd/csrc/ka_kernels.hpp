@@ -571,48 +571,9 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
         for (int dd = 0; dd < D; ++dd) {
             const uint32_t t = tb + dd;
             if (t < T) {
-                // A. band of frame t+1; re-label the lanes whose block has been passed by lo.  The band is a
-                // function of floor(L*t/T): nothing to do in the frames where that does not move (every
-                // instruction costs issue time here, scalar ones included)
-                uint32_t nlo = lo, nhi = hi;
-                bool relabeled = false;
-                bool relabel_lane = false;
-                bool moved = false;
-                rem += dr;
-                if (__builtin_expect(rem >= step_thr, 0)) {
-                    asm volatile("" ::: "memory");  // a real branch: the common frame pays an add, a compare and a jump
-                    q += dq;
-                    if (rem >= T) { rem -= T; ++q; }
-                    if (t + 1 != T) {   // no frame T: keep the last band and labels
-                        moved = true;
-                        const int32_t dlo = (int32_t)q - (int32_t)halfB;  // signed on purpose: s_max_i32, not a VALU usubsat
-                        nlo = (uint32_t)(dlo > 0 ? dlo : 0);
-                        nhi = (L - nlo < B) ? L : nlo + B;
-                        if ((nlo >> 4) != blo) {
-                            blo = nlo >> 4;
-                            const int nb = (int)blo + ((lane - (int)blo) & 63);
-                            if (nb != blk) {
-                                blk = nb;
-                                load_block_labels(labx, blk, la);
-                                relabel_lane = true;
-                                // consume the loads HERE: otherwise the wait for them lands at the merge
-                                // point as an every-frame s_waitcnt vmcnt(0) that also drains the row
-                                // prefetches and the back-pointer stores
-#pragma unroll
-                                for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(la[i]));
-                            }
-                            relabeled = true;
-                        }
-                    }
-                }
-                // B. row t+1 (its emissions are gathered while frame t is computed).  It was issued D-1
-                // frames ago; since then (D-2) frames each issued one row load, and the group store that
-                // follows frame 4k+3 lies in between unless dd = 3 (rare label reloads only add younger ops)
-                if (!LITE && dd < D - 1) row_wait<D - 1>(rows[(dd + 1) % D]); else row_wait<D - 2>(rows[(dd + 1) % D]);
-                const float rn = rows[(dd + 1) % D];
-                e0[(dd + 1) & 1] = first_lane(rn);
-                if constexpr (LITE) absum += __builtin_fabsf(rn);
-                // C. frame t
+                // Halos of frame t, then the reset of lanes re-labelled in frame t-1 (they still held the scores of
+                // their OLD block, which their right neighbour has just read as its halo).  Done before step A so that
+                // A can write the flags of the NEXT frame in place (no per-frame copies of flags and band limits).
                 float h1 = wave_ror1(sc[15]), h2 = wave_ror1(sc[14]), h3 = wave_ror1(sc[13]);
                 if (__builtin_expect(pend_reset, 0)) {
                     asm volatile("" ::: "memory");  // keep this rare block a real branch (no if-conversion)
@@ -627,7 +588,46 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
 #pragma unroll
                     for (int k = 0; k < 16; ++k) sc[k] = reset_lane ? NINF : sc[k];
                     pres2 = reset_lane ? 0u : pres2;
+                    pend_reset = false;
                 }
+                // A. band of frame t+1; re-label the lanes whose block has been passed by lo.  The band is a
+                // function of floor(L*t/T): nothing to do in the frames where that does not move (every
+                // instruction costs issue time here, scalar ones included)
+                bool moved = false;
+                rem += dr;
+                if (__builtin_expect(rem >= step_thr, 0)) {
+                    asm volatile("" ::: "memory");  // a real branch: the common frame pays an add, a compare and a jump
+                    q += dq;
+                    if (rem >= T) { rem -= T; ++q; }
+                    if (t + 1 != T) {   // no frame T: keep the last band and labels
+                        moved = true;
+                        const int32_t dlo = (int32_t)q - (int32_t)halfB;  // signed on purpose: s_max_i32, not a VALU usubsat
+                        const uint32_t nlo = (uint32_t)(dlo > 0 ? dlo : 0);
+                        if ((nlo >> 4) != blo) {
+                            blo = nlo >> 4;
+                            const int nb = (int)blo + ((lane - (int)blo) & 63);
+                            reset_lane = nb != blk;
+                            if (nb != blk) {
+                                blk = nb;
+                                load_block_labels(labx, blk, la);
+                                // consume the loads HERE: otherwise the wait for them lands at the merge
+                                // point as an every-frame s_waitcnt vmcnt(0) that also drains the row
+                                // prefetches and the back-pointer stores
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(la[i]));
+                            }
+                            pend_reset = true;
+                        }
+                    }
+                }
+                // B. row t+1 (its emissions are gathered while frame t is computed).  It was issued D-1
+                // frames ago; since then (D-2) frames each issued one row load, and the group store that
+                // follows frame 4k+3 lies in between unless dd = 3 (rare label reloads only add younger ops)
+                if (!LITE && dd < D - 1) row_wait<D - 1>(rows[(dd + 1) % D]); else row_wait<D - 2>(rows[(dd + 1) % D]);
+                const float rn = rows[(dd + 1) % D];
+                e0[(dd + 1) & 1] = first_lane(rn);
+                if constexpr (LITE) absum += __builtin_fabsf(rn);
+                // C. frame t
                 uint32_t word = 0;
                 frame_cells<M, ZL, 15, LITE>(sc, h1, h2, h3, e, vz, e0[dd & 1], mk, NINF, word, la, rn);
                 gw[dd] = word;
@@ -637,23 +637,26 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                 rows[dd] = row_load(lane_off, row_ahead);
                 row_ahead += t + D + 1 < T ? ld : 0;
                 // D. lane masks of frame t+1
-                if (moved && (nlo != lo || nhi != hi)) {
-                    if (nhi - hi <= 1u && nlo - lo <= 1u) {
-                        if (nhi != hi) band_toggle(mk, hi);
-                        if (nlo != lo) band_toggle(mk, lo);
-                    } else {
-                        band_rebuild(mk, nlo, nhi);
-                    }
-                    band2 = band_pairs(nlo, nhi, blk);
-                    lo = nlo;
-                    hi = nhi;
-                    if (ZL && relabeled) {
+                if (moved) {
+                    const int32_t dlo = (int32_t)q - (int32_t)halfB;
+                    const uint32_t nlo = (uint32_t)(dlo > 0 ? dlo : 0);
+                    const uint32_t nhi = (L - nlo < B) ? L : nlo + B;
+                    if (nlo != lo || nhi != hi) {
+                        if (nhi - hi <= 1u && nlo - lo <= 1u) {
+                            if (nhi != hi) band_toggle(mk, hi);
+                            if (nlo != lo) band_toggle(mk, lo);
+                        } else {
+                            band_rebuild(mk, nlo, nhi);
+                        }
+                        band2 = band_pairs(nlo, nhi, blk);
+                        lo = nlo;
+                        hi = nhi;
+                        if (ZL && pend_reset) {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) vz[i] = la[i] == 0 ? NINF : __builtin_inff();
+                            for (int i = 0; i < 8; ++i) vz[i] = la[i] == 0 ? NINF : __builtin_inff();
+                        }
                     }
                 }
-                pend_reset = relabeled;
-                reset_lane = relabel_lane;
             }
         }
         if constexpr (!LITE) {
