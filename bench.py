@@ -198,7 +198,7 @@ def main():
         value = frames_per_step * args.steps / elapsed
         fwd_b, job_b, wbar, survey_fwd_b = algorithmic_bytes_per_frame()
         fwd_s = float(np.mean(fwd_ms)) * 1e-3
-        checkpointed = args.mode in ("auto", "wave") and B > 1024   # the form KA_MODE_AUTO takes at this batch size
+        checkpointed = (args.mode == "auto" and B > 256) or args.mode == "wave"   # the form KA_MODE_AUTO takes at this batch size
         if not checkpointed:     # every back-pointer stored: SURVEY.md 8d's bytes are this form's own
             fwd_b = survey_fwd_b
             job_b = survey_fwd_b + 12.25 + 4.0 * V / 2
@@ -228,8 +228,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same batch size)" if traffic else None,
                          "kernel": "forward_ck_kernel<4,false>" if checkpointed else
-                                   ("forward_w16_kernel<4,false>" if args.mode == "wave_exact" or (args.mode == "wave" and B <= 1024)
-                                    else "forward_wg4_kernel<4,false>"),
+                                   ("forward_w16_kernel<4,false>" if args.mode == "wave_exact" else "forward_wg4_kernel<4,false>"),
                          "kernel_ms": fwd_s * 1e3,
                          "algorithmic_bytes_per_frame": fwd_b, "mean_band_width": wbar,
                          "survey_8d_bytes_per_frame": survey_fwd_b,

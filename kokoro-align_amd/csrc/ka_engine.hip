@@ -33,8 +33,10 @@ int fail(int code, const std::string &msg)
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
-// KA_MODE_AUTO: up to this many lattices per call use the 4-wavefront form (256 CUs x 4 lattices)
-constexpr int32_t kAutoWorkgroupMaxLattices = 1024;
+// KA_MODE_AUTO: up to this many lattices per call use the 4-wavefront form.  Measured on cfg2 lattices
+// (tools/sweep_modes.sh): the two forms tie up to 256 lattices (23 ms), at 512 the checkpointed wave form is
+// ahead (23.9 vs 28.1 ms), at 1024 by 24.1 vs 39.8 ms.
+constexpr int32_t kAutoWorkgroupMaxLattices = 256;
 
 struct Shape {
     int64_t T, S, L, W;
