@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Static check of the compiled kernels (ka_engine.s from `make -C kokoro-align_amd/csrc asm`).
+
+The forward / backtrace kernels issue their prefetch loads from inline asm and release the destination
+registers with counted s_waitcnt statements.  hipcc does not know those registers are in flight: if its
+register allocation makes it COPY one of them (v_mov from a register that an asm load writes) before the load
+has landed - at a loop back-edge when it rotates registers, at a merge, ahead of a multi-register release - the
+copy reads garbage.  That produced wrong paths under memory pressure and memory faults during development
+(DESIGN.md section 7).
+
+The check walks each kernel's instructions in program order with the hardware's rule (vmcnt is an in-order
+counter: after `s_waitcnt vmcnt(N)` everything but the N youngest vector-memory operations has completed) and
+reports every v_mov / DPP mov whose SOURCE is a register written by an inline-asm load that is not yet known to
+have landed.  Program order is not execution order across branches, so this is a lint, not a proof: it is
+exact for the straight-line unrolled frame code and for the copies a compiler puts in front of a back-edge.
+
+    python tools/lint_inflight.py [path/to/ka_engine.s]      exit status 1 when something is reported
+"""
+import os
+import re
+import sys
+
+KERNELS = ("forward_ck", "forward_w16", "forward_wg4", "backtrace_rc", "backtrace_w16")
+VMEM = re.compile(r"\s*(global_load|global_store|buffer_load|buffer_store|flat_load|flat_store|global_atomic)\w*\s+(.*)")
+WAIT = re.compile(r"\s*s_waitcnt\s+(.*)")
+MOV = re.compile(r"\s*v_mov_b32(?:_e32|_dpp|_e64)?\s+(v[0-9]+),\s*(v[0-9]+)\b")
+MOV64 = re.compile(r"\s*v_mov_b64(?:_e32)?\s+v\[([0-9]+):([0-9]+)\],\s*v\[([0-9]+):([0-9]+)\]")
+
+
+def regs(tok):
+    tok = tok.strip()
+    if tok.startswith("v["):
+        a, b = map(int, tok[2:-1].split(":"))
+        return [f"v{i}" for i in range(a, b + 1)]
+    return [tok] if re.fullmatch(r"v[0-9]+", tok) else []
+
+
+def check(path):
+    txt = open(path).read()
+    report, total = [], 0
+    for k in re.split(r"\n(?=_ZN2ka\w+:)", txt):
+        m = re.match(r"(_ZN2ka\w+):", k)
+        if not m or not any(x in m.group(1) for x in KERNELS):
+            continue
+        issued = 0                 # vector-memory operations issued so far (program order)
+        pending = {}               # register -> issue index of the inline-asm load that writes it
+        in_asm = False
+        found = []
+        for ln in k.split("\n"):
+            if "ASMSTART" in ln:
+                in_asm = True
+                continue
+            if "ASMEND" in ln:
+                in_asm = False
+                continue
+            mv = VMEM.match(ln)
+            if mv:
+                issued += 1
+                if mv.group(1) == "global_load":
+                    dst = mv.group(2).split(",")[0]
+                    for r in regs(dst):
+                        if in_asm:
+                            pending[r] = issued
+                        else:
+                            pending.pop(r, None)      # a compiler-tracked load: hipcc waits for it itself
+                continue
+            mw = WAIT.match(ln)
+            if mw:
+                mc = re.search(r"vmcnt\((\d+)\)", mw.group(1))
+                if mc:
+                    landed = issued - int(mc.group(1))
+                    for r in [r for r, i in pending.items() if i <= landed]:
+                        del pending[r]
+                continue
+            mm = MOV.match(ln)
+            srcs = []
+            if mm:
+                srcs = [mm.group(2)]
+            else:
+                m64 = MOV64.match(ln)
+                if m64:
+                    srcs = [f"v{i}" for i in range(int(m64.group(3)), int(m64.group(4)) + 1)]
+            for r in srcs:
+                if r in pending:
+                    found.append(ln.strip())
+            # any other instruction that WRITES a pending register ends its life as a load destination
+            mo = re.match(r"\s*(v_\w+|ds_\w+)\s+(v\[?[0-9:]+\]?)", ln)
+            if mo and not ln.lstrip().startswith(("v_cmp", "v_cmpx")):
+                for r in regs(mo.group(2)):
+                    if r in pending and not srcs:
+                        pending.pop(r, None)
+        report.append((m.group(1), found))
+        total += len(found)
+    return report, total
+
+
+if __name__ == "__main__":
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "kokoro-align_amd", "csrc", "ka_engine.s")
+    rep, total = check(path)
+    for name, found in rep:
+        if found:
+            print(f"{name}: {len(found)} copies of registers whose load may be in flight, e.g. {found[:3]}")
+    print(f"{len(rep)} kernels checked, {total} suspicious copies")
+    sys.exit(1 if total else 0)
