@@ -152,6 +152,14 @@ __device__ __forceinline__ float row_load(uint32_t lane_byte_off, const void *ro
     asm volatile("global_load_dword %0, %1, %2" : "=v"(r) : "v"(lane_byte_off), "s"(row_base) : "memory");
     return r;
 }
+// Reload of a loop-carried row register: the destination is TIED to the register's previous (dead) contents, so
+// the register allocator has to keep the row in one physical register around the loop.  With a plain output it
+// may rotate the loop-carried registers with v_mov copies at the back-edge - copies of registers whose loads
+// have not landed (tools/lint_inflight.py checks the compiled code for exactly that).
+__device__ __forceinline__ void row_reload(float &r, uint32_t lane_byte_off, const void *row_base /* wave-uniform */)
+{
+    asm volatile("global_load_dword %0, %1, %2" : "+v"(r) : "v"(lane_byte_off), "s"(row_base) : "memory");
+}
 // wait until at most N younger vector-memory operations are outstanding, then release `r`
 template <int N>
 __device__ __forceinline__ void row_wait(float &r)
@@ -634,7 +642,7 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                 // live <=> in band and (moved in from a live state, or stayed on a live state)
                 if constexpr (!LITE) pres2 = live_pairs(pres2, word, band2);
                 // prefetch the row of frame t+D (the last row again once there is none: never consumed)
-                rows[dd] = row_load(lane_off, row_ahead);
+                row_reload(rows[dd], lane_off, row_ahead);
                 row_ahead += t + D + 1 < T ? ld : 0;
                 // D. lane masks of frame t+1
                 if (moved) {
@@ -965,7 +973,7 @@ __device__ __forceinline__ void forward_wg4(const Lattice &d, int32_t *meta)
                 keep = quad == dd ? x : keep;
                 {
                     const uint32_t tt = t + D < T ? t + D : T - 1;
-                    rows[dd] = row_load(lane_off, lp + (size_t)tt * ld);
+                    row_reload(rows[dd], lane_off, lp + (size_t)tt * ld);
                 }
                 // D. lane masks of frame t+1
                 if (nlo != lo || nhi != hi) {
