@@ -894,6 +894,8 @@ __device__ __forceinline__ void forward_wg4(const Lattice &d, int32_t *meta)
     const uint32_t store_off = (uint32_t)tid * 4u;       // [t/4][block = tid>>2][t%4 = tid&3] dwords: thread tid keeps frame tid&3
     const int prev_wave = (int)((wv + 3u) & 3u);
     uint32_t keep = 0;
+    uint32_t step_thr = dq != 0 ? 0u : T;   // floor(L*t/T) moves in this frame <=> rem + dr >= step_thr
+    asm("" : "+s"(step_thr));
 
     if (lane == 63) {
         s_halo[0][wv][0] = NINF; s_halo[0][wv][1] = NINF; s_halo[0][wv][2] = NINF; s_halo[0][wv][3] = 0.0f;
@@ -906,35 +908,8 @@ __device__ __forceinline__ void forward_wg4(const Lattice &d, int32_t *meta)
             const uint32_t t = tb + dd;
             if (t < T) {
                 const int par = (int)(t & 1u);
-                // A. band of frame t+1; re-label the threads whose block has been passed by lo
-                uint32_t nq = q + dq, nrem = rem + dr;
-                if (nrem >= T) { nrem -= T; ++nq; }
-                const int32_t dlo = (int32_t)nq - (int32_t)halfB;
-                uint32_t nlo = (uint32_t)(dlo > 0 ? dlo : 0);
-                uint32_t nhi = (L - nlo < B) ? L : nlo + B;
-                if (t + 1 == T) { nlo = lo; nhi = hi; }
-                bool relabeled = false, relabel_lane = false;
-                if ((nlo >> 4) != blo) {
-                    blo = nlo >> 4;
-                    const int nb = (int)blo + ((sub - (int)blo) & 63);
-                    if (nb != blk) {
-                        blk = nb;
-                        la[0] = labx[(size_t)blk * 8 + 2 * quad];
-                        la[1] = labx[(size_t)blk * 8 + 2 * quad + 1];
-                        relabel_lane = true;
-                        asm volatile("" : "+v"(la[0]), "+v"(la[1]));
-                    }
-                    relabeled = true;
-                }
-                // B. emissions of frame t+1
-                {
-                    if (dd < D - 1) row_wait<D - 1>(rows[(dd + 1) % D]); else row_wait<D - 2>(rows[(dd + 1) % D]);   // as in forward_w16
-                    const float rn = rows[(dd + 1) % D];
-                    e[(dd + 1) & 1][0] = bperm(la[0], rn);
-                    e[(dd + 1) & 1][1] = bperm(la[1], rn);
-                    e0[(dd + 1) & 1] = first_lane(rn);
-                }
-                // C. frame t.  Left neighbours: previous lane (DPP), or for lane 0 the previous wave's lane 63 (LDS)
+                // Halos of frame t.  Left neighbours: previous lane (DPP), or for lane 0 the previous wave's lane 63 (LDS).
+                // Then the reset of threads re-labelled in frame t-1, ahead of step A (as in forward_w16).
                 float h1 = wave_ror1(sc[3]), h2 = wave_ror1(sc[2]), h3 = wave_ror1(sc[1]);
                 {
                     const float l1 = s_halo[par][prev_wave][0], l2 = s_halo[par][prev_wave][1], l3 = s_halo[par][prev_wave][2];
@@ -953,7 +928,44 @@ __device__ __forceinline__ void forward_wg4(const Lattice &d, int32_t *meta)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) sc[k] = reset_lane ? NINF : sc[k];
                     pres2 = reset_lane ? 0u : pres2;
+                    pend_reset = false;
+                    reset_lane = false;
                 }
+                // A. band of frame t+1; re-label the threads whose block has been passed by lo - only in the frames
+                // where floor(L*t/T) moves
+                bool moved = false;
+                rem += dr;
+                if (__builtin_expect(rem >= step_thr, 0)) {
+                    asm volatile("" ::: "memory");
+                    q += dq;
+                    if (rem >= T) { rem -= T; ++q; }
+                    if (t + 1 != T) {   // no frame T: keep the last band and labels
+                        moved = true;
+                        const int32_t dlo = (int32_t)q - (int32_t)halfB;
+                        const uint32_t nlo = (uint32_t)(dlo > 0 ? dlo : 0);
+                        if ((nlo >> 4) != blo) {
+                            blo = nlo >> 4;
+                            const int nb = (int)blo + ((sub - (int)blo) & 63);
+                            reset_lane = nb != blk;
+                            if (nb != blk) {
+                                blk = nb;
+                                la[0] = labx[(size_t)blk * 8 + 2 * quad];
+                                la[1] = labx[(size_t)blk * 8 + 2 * quad + 1];
+                                asm volatile("" : "+v"(la[0]), "+v"(la[1]));
+                            }
+                            pend_reset = true;
+                        }
+                    }
+                }
+                // B. emissions of frame t+1
+                {
+                    if (dd < D - 1) row_wait<D - 1>(rows[(dd + 1) % D]); else row_wait<D - 2>(rows[(dd + 1) % D]);   // as in forward_w16
+                    const float rn = rows[(dd + 1) % D];
+                    e[(dd + 1) & 1][0] = bperm(la[0], rn);
+                    e[(dd + 1) & 1][1] = bperm(la[1], rn);
+                    e0[(dd + 1) & 1] = first_lane(rn);
+                }
+                // C. frame t
                 uint32_t word = 0;
                 frame_cells4<M, ZL, 3>(sc, h1, h2, h3, e[dd & 1], vz, e0[dd & 1], mk, NINF, word);
                 // hand this wave's top three scores (and whether lane 63 will be re-labelled) to the next wave
@@ -961,7 +973,7 @@ __device__ __forceinline__ void forward_wg4(const Lattice &d, int32_t *meta)
                     s_halo[par ^ 1][wv][0] = sc[3];
                     s_halo[par ^ 1][wv][1] = sc[2];
                     s_halo[par ^ 1][wv][2] = sc[1];
-                    s_halo[par ^ 1][wv][3] = relabel_lane ? 1.0f : 0.0f;
+                    s_halo[par ^ 1][wv][3] = (pend_reset && reset_lane) ? 1.0f : 0.0f;
                 }
                 {
                     pres2 = live_pairs(pres2, word, band2);
@@ -976,25 +988,26 @@ __device__ __forceinline__ void forward_wg4(const Lattice &d, int32_t *meta)
                     row_reload(rows[dd], lane_off, lp + (size_t)tt * ld);
                 }
                 // D. lane masks of frame t+1
-                if (nlo != lo || nhi != hi) {
-                    if ((nhi - hi) + (nlo - lo) <= 6u) {
-                        for (uint32_t p = hi; p < nhi; ++p) band_toggle4(mk, p, wv);
-                        for (uint32_t p = lo; p < nlo; ++p) band_toggle4(mk, p, wv);
-                    } else {
-                        band_rebuild4(mk, nlo, nhi, wv);
-                    }
-                    band2 = pair_mask4((int)nhi - (blk * 16 + 4 * quad)) & ~pair_mask4((int)nlo - (blk * 16 + 4 * quad));
-                    lo = nlo;
-                    hi = nhi;
-                    if (ZL && relabeled) {
+                if (moved) {
+                    const int32_t dlo = (int32_t)q - (int32_t)halfB;
+                    const uint32_t nlo = (uint32_t)(dlo > 0 ? dlo : 0);
+                    const uint32_t nhi = (L - nlo < B) ? L : nlo + B;
+                    if (nlo != lo || nhi != hi) {
+                        if ((nhi - hi) + (nlo - lo) <= 6u) {
+                            for (uint32_t p = hi; p < nhi; ++p) band_toggle4(mk, p, wv);
+                            for (uint32_t p = lo; p < nlo; ++p) band_toggle4(mk, p, wv);
+                        } else {
+                            band_rebuild4(mk, nlo, nhi, wv);
+                        }
+                        band2 = pair_mask4((int)nhi - (blk * 16 + 4 * quad)) & ~pair_mask4((int)nlo - (blk * 16 + 4 * quad));
+                        lo = nlo;
+                        hi = nhi;
+                        if (ZL && pend_reset) {
 #pragma unroll
-                        for (int i = 0; i < 2; ++i) vz[i] = la[i] == 0 ? NINF : __builtin_inff();
+                            for (int i = 0; i < 2; ++i) vz[i] = la[i] == 0 ? NINF : __builtin_inff();
+                        }
                     }
                 }
-                q = nq;
-                rem = nrem;
-                pend_reset = relabeled;
-                reset_lane = relabel_lane;
                 // one rendezvous per frame: LDS writes of this frame are visible before anyone reads them in the next
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
