@@ -896,6 +896,7 @@ __device__ __forceinline__ void forward_wg4(const Lattice &d, int32_t *meta)
     uint32_t keep = 0;
     uint32_t step_thr = dq != 0 ? 0u : T;   // floor(L*t/T) moves in this frame <=> rem + dr >= step_thr
     asm("" : "+s"(step_thr));
+    const char *row_ahead = lp + (size_t)(D < T ? D : T - 1) * ld;   // row min(t+D, T-1) of the current frame t
 
     if (lane == 63) {
         s_halo[0][wv][0] = NINF; s_halo[0][wv][1] = NINF; s_halo[0][wv][2] = NINF; s_halo[0][wv][3] = 0.0f;
@@ -983,10 +984,9 @@ __device__ __forceinline__ void forward_wg4(const Lattice &d, int32_t *meta)
                 x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
                 x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
                 keep = quad == dd ? x : keep;
-                {
-                    const uint32_t tt = t + D < T ? t + D : T - 1;
-                    row_reload(rows[dd], lane_off, lp + (size_t)tt * ld);
-                }
+                // prefetch the row of frame t+D (the last row again once there is none: never consumed)
+                row_reload(rows[dd], lane_off, row_ahead);
+                row_ahead += t + D + 1 < T ? ld : 0;
                 // D. lane masks of frame t+1
                 if (moved) {
                     const int32_t dlo = (int32_t)q - (int32_t)halfB;
