@@ -107,7 +107,7 @@ int ka_batch_finish(ka_engine *e, float *total_score, int32_t *status);
  *   KA_MODE_WAVE_EXACT  one wavefront per lattice, every back-pointer stored (2 bits per band cell).
  *   KA_MODE_WORKGROUP   four wavefronts per lattice with an LDS hand-off per frame (latency: a single file, a
  *                       book's few dozen chapters); back-pointers stored.
- *   KA_MODE_AUTO        (default) WORKGROUP up to 256 lattices per call, WAVE above.
+ *   KA_MODE_AUTO        (default) WORKGROUP up to 512 lattices per call, WAVE above.
  * Results are identical in every form. */
 #define KA_MODE_AUTO 0
 #define KA_MODE_WAVE 1

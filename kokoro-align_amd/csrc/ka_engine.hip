@@ -34,9 +34,9 @@ int fail(int code, const std::string &msg)
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 // KA_MODE_AUTO: up to this many lattices per call use the 4-wavefront form.  Measured on cfg2 lattices
-// (tools/sweep_modes.sh): the two forms tie up to 256 lattices (23 ms), at 512 the checkpointed wave form is
-// ahead (23.9 vs 28.1 ms), at 1024 by 24.1 vs 39.8 ms.
-constexpr int32_t kAutoWorkgroupMaxLattices = 256;
+// (tools/sweep_modes.sh): 20.8 vs 23.0 ms at 256 lattices, 23.2 vs 23.9 ms at 512, 30.3 vs 24.1 ms at 1024
+// (four-wavefront form vs checkpointed one-wavefront form).
+constexpr int32_t kAutoWorkgroupMaxLattices = 512;
 
 struct Shape {
     int64_t T, S, L, W;
