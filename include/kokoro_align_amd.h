@@ -129,6 +129,22 @@ int ka_engine_last_kernel_ms(ka_engine *e, float ms[4]);
 int ka_log_softmax_f32(const float *logits, float *log_probs, int64_t T, int32_t V,
                        int64_t ld_in, int64_t ld_out, void *stream);
 
+/*
+ * One time step of one layer of the log-prob producer's bidirectional LSTM (AudioToChar, kokoro_align/train.py:54-65;
+ * called from predict, train.py:201-231), both directions at once, for the n sequences that are still running
+ * (sequences sorted by length, longest first: the running ones are a prefix).  Fused element-wise part:
+ *   gates = gin[rows[dir][s], dir*4H : (dir+1)*4H] + rec[dir][s]          (PyTorch order i, f, g, o)
+ *   c[dir][s] = sigmoid(f)*c[dir][s] + sigmoid(i)*tanh(g);   h[dir][s] = sigmoid(o)*tanh(c[dir][s])
+ *   out[rows[dir][s], dir*H : (dir+1)*H] = h[dir][s]
+ * gin [frames, ldg >= 8H] = x @ W_ih^T + b_ih + b_hh of both directions (one library GEMM per layer),
+ * rec [2][n][4H] = h @ W_hh^T (one batched library GEMM per step; *_dir_stride = elements between directions),
+ * rows [2][..] int32 = frame row of sequence s at this step (forward: offset+t, backward: offset+len-1-t).
+ * All pointers are device pointers.
+ */
+int ka_lstm_step_f32(const float *gin, int64_t ldg, const float *rec, int64_t rec_dir_stride, float *c, float *h,
+                     int64_t state_dir_stride, float *out, int64_t ldo, const int32_t *rows, int64_t rows_dir_stride,
+                     int32_t n, int32_t H, void *stream);
+
 /* Bit-reproducible synthetic inputs generated in HBM (same definition as the CPU oracle's
  * hash generator):  lp[t,c] = -8*u24(mix(seed, t*V+c)),
  * labels[k] = 1 + mix(seed^salt, k) % (V-1). */

@@ -491,6 +491,20 @@ int ka_log_softmax_f32(const float *logits, float *log_probs, int64_t T, int32_t
     return KA_OK;
 }
 
+int ka_lstm_step_f32(const float *gin, int64_t ldg, const float *rec, int64_t rec_dir_stride, float *c, float *h,
+                     int64_t state_dir_stride, float *out, int64_t ldo, const int32_t *rows, int64_t rows_dir_stride,
+                     int32_t n, int32_t H, void *stream)
+{
+    if (!gin || !rec || !c || !h || !out || !rows || n < 0 || H < 1 || ldg < 8 * (int64_t)H || ldo < 2 * (int64_t)H)
+        return fail(KA_ERR_BAD_ARGS, "ka_lstm_step_f32: bad arguments");
+    if (n == 0) return KA_OK;
+    const int64_t blocks = ((int64_t)n * H + 255) / 256;
+    hipLaunchKernelGGL(ka::lstm_step_kernel, dim3((unsigned)blocks, 2), dim3(256), 0, (hipStream_t)stream, gin, ldg, rec,
+                       rec_dir_stride, c, h, state_dir_stride, out, ldo, rows, rows_dir_stride, n, H);
+    KA_HIP(hipGetLastError());
+    return KA_OK;
+}
+
 int ka_hash_logprobs_batch_f32(float *dev_log_probs, int32_t n, int64_t T, int32_t V, int64_t ld, int64_t lattice_stride,
                                uint64_t seed0, void *stream)
 {

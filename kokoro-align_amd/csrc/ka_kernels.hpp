@@ -1544,6 +1544,38 @@ __global__ __launch_bounds__(256) void log_softmax_kernel(const float *__restric
 }
 
 // ---------------------------------------------------------------------------------------
+// LSTM cell update of the log-prob producer (AudioToChar, kokoro_align/train.py:54-65), one time step of one
+// layer, both directions: gates = gin[row] + rec, PyTorch gate order (i, f, g, o);
+//   c = sigmoid(f)*c + sigmoid(i)*tanh(g);  h = sigmoid(o)*tanh(c)
+// gin holds x_t @ W_ih^T + b_ih + b_hh of every frame (one library GEMM per layer), rec = h_{t-1} @ W_hh^T of
+// the n sequences still running (one batched library GEMM per step); this kernel is the fused element-wise
+// part and scatters h into the layer's output rows.  grid: x = ceil(n*H/256), y = direction (0 fwd, 1 bwd).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_step_kernel(const float *__restrict__ gin, int64_t ldg,
+                                                        const float *__restrict__ rec, int64_t rec_dir_stride,
+                                                        float *__restrict__ c, float *__restrict__ h, int64_t state_dir_stride,
+                                                        float *__restrict__ out, int64_t ldo,
+                                                        const int32_t *__restrict__ rows, int64_t rows_dir_stride, int n, int H)
+{
+    const int dir = blockIdx.y;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)n * H) return;
+    const int s = (int)(idx / H), j = (int)(idx % H);
+    const int64_t row = rows[(size_t)dir * rows_dir_stride + s];
+    const float *g = gin + (size_t)row * ldg + (size_t)dir * 4 * H;
+    const float *r = rec + (size_t)dir * rec_dir_stride + (size_t)s * 4 * H;
+    const float gi = g[j] + r[j], gf = g[H + j] + r[H + j], gg = g[2 * H + j] + r[2 * H + j], go = g[3 * H + j] + r[3 * H + j];
+    const float si = 1.0f / (1.0f + expf(-gi)), sf = 1.0f / (1.0f + expf(-gf)), so = 1.0f / (1.0f + expf(-go));
+    float *cs = c + (size_t)dir * state_dir_stride + (size_t)s * H;
+    float *hs = h + (size_t)dir * state_dir_stride + (size_t)s * H;
+    const float cn = sf * cs[j] + si * tanhf(gg);
+    const float hn = so * tanhf(cn);
+    cs[j] = cn;
+    hs[j] = hn;
+    out[(size_t)row * ldo + (size_t)dir * H + j] = hn;
+}
+
+// ---------------------------------------------------------------------------------------
 // hash generator of synthetic inputs (definition: include/kokoro_align_amd.h)
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t idx)

@@ -49,3 +49,98 @@ def segment_logits(model, segments, device=None, batch_size=128):
         for j, n in enumerate(lengths.tolist()):
             out.append(logits[:n, j, :])
     return out
+
+
+@torch.no_grad()
+def lstm_logits_device(model, data, indices, device=None):
+    """Logits of every frame of an IndexDataArray (``data`` [rows, n_mfcc], ``indices`` = cumulative segment ends,
+    kokoro_align/preprocess.py:12-35), [rows, vocab] on ``device`` in the file's row order - what the reference's
+    predict() writes to *.logits.npz (train.py:215-231) - computed for ALL segments at once.
+
+    The reference runs the network file by file, 128 segments per call; MIOpen's LSTM then spends ~100 us per
+    time step whatever the batch, and refuses large batches.  Here every layer is
+      * one library GEMM for the input projections of all frames of all segments (x @ W_ih^T + b_ih + b_hh),
+      * per time step ONE batched library GEMM (h @ W_hh^T, both directions) and ONE fused HIP kernel
+        (ka_lstm_step_f32: gate non-linearities, cell update, scatter of h into the layer output),
+    with the segments sorted by length so that the sequences still running are a prefix.  Inference only (no
+    dropout); float32; equal to the PyTorch network within rounding (tests: 1e-4).
+    """
+    import numpy as np
+    from . import _lib
+    lib = _lib.load_library()
+    device = torch.device(device) if device is not None else next(model.parameters()).device
+    if device.type != "cuda":
+        raise _lib.KAError("lstm_logits_device needs a GPU (the CPU path is segment_logits)")
+    ends = np.asarray(indices, dtype=np.int64).reshape(-1)
+    n = int(ends.size)
+    total = int(ends[-1]) if n else 0
+    x_file = torch.as_tensor(data, dtype=torch.float32)[:total].to(device)
+    if total == 0:
+        return torch.zeros((0, model.dense.out_features), dtype=torch.float32, device=device)
+    starts = np.concatenate([[0], ends[:-1]])
+    lens = ends - starts
+    keep = np.nonzero(lens > 0)[0]                      # empty segments contribute no rows
+    order = keep[np.argsort(-lens[keep], kind="stable")]
+    n = int(order.size)
+    slen = lens[order]
+    offs = np.concatenate([[0], np.cumsum(slen)[:-1]])  # row offsets in the length-sorted layout
+    max_len = int(slen[0])
+    # sorted row r of segment i (sorted position s): file row starts[order[s]] + (r - offs[s])
+    seg_of_row = np.repeat(np.arange(n), slen)
+    perm = torch.from_numpy((starts[order][seg_of_row] + (np.arange(total) - offs[seg_of_row])).astype(np.int64)).to(device)
+    x = x_file.index_select(0, perm)
+    # sequences still running at step t (lengths are sorted descending), frame rows of every (direction, step, sequence)
+    n_run = (n - np.searchsorted(slen[::-1], np.arange(max_len), side="right")).tolist()
+    d_offs = torch.from_numpy(offs).to(device)
+    d_len = torch.from_numpy(slen).to(device)
+    steps = torch.arange(max_len, dtype=torch.int64, device=device).unsqueeze(1)
+    rows = torch.stack([d_offs.unsqueeze(0) + steps, d_offs.unsqueeze(0) + d_len.unsqueeze(0) - 1 - steps], 0)   # [2, max_len, n]
+    rows = rows.clamp_(0, total - 1).to(torch.int32).contiguous()
+    rows_ptr, rows_step, rows_dir = rows.data_ptr(), n * 4, rows.stride(0)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    H = model.hidden_dim
+    sd = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in model.state_dict().items()}
+    inp = x
+    for layer in range(model.lstm.num_layers):
+        sfx = [f"_l{layer}", f"_l{layer}_reverse"]
+        w_ih = torch.cat([sd["lstm.weight_ih" + s] for s in sfx], 0)                       # [8H, in]
+        bias = torch.cat([sd["lstm.bias_ih" + s] + sd["lstm.bias_hh" + s] for s in sfx], 0)  # [8H]
+        w_hh_t = torch.stack([sd["lstm.weight_hh" + s].t().contiguous() for s in sfx], 0)  # [2, H, 4H]
+        gin = torch.addmm(bias, inp, w_ih.t())                                             # [total, 8H]
+        out = torch.empty((total, 2 * H), dtype=torch.float32, device=device)
+        h = torch.zeros((2, n, H), dtype=torch.float32, device=device)
+        c = torch.zeros((2, n, H), dtype=torch.float32, device=device)
+        rec = torch.empty((2, n, 4 * H), dtype=torch.float32, device=device)
+        args = (gin.data_ptr(), gin.stride(0), rec.data_ptr(), rec.stride(0), c.data_ptr(), h.data_ptr(), h.stride(0),
+                out.data_ptr(), out.stride(0))
+        step = lib.ka_lstm_step_f32
+        for t in range(max_len):
+            # fixed shape on purpose (finished sequences included, their result is ignored): a new GEMM shape
+            # per step would cost a library heuristic lookup each
+            torch.bmm(h, w_hh_t, out=rec)                                                  # [2, n, 4H]
+            rc = step(*args, rows_ptr + t * rows_step, rows_dir, n_run[t], H, stream)
+            if rc:
+                _lib.check(rc, "ka_lstm_step_f32")
+        del gin
+        inp = out
+    logits_sorted = torch.addmm(sd["dense.bias"], inp, sd["dense.weight"].t())
+    logits = torch.empty_like(logits_sorted)
+    logits.index_copy_(0, perm, logits_sorted)           # back to the file's row order
+    return logits
+
+
+@torch.no_grad()
+def segment_logits_device(model, segments, device=None):
+    """``segment_logits`` through ``lstm_logits_device``: list of [len_i, n_mfcc] -> list of [len_i, vocab] on the
+    device, in the order given."""
+    import numpy as np
+    if len(segments) == 0:
+        return []
+    lens = [int(s.shape[0]) for s in segments]
+    data = torch.cat([torch.as_tensor(s, dtype=torch.float32) for s in segments], dim=0)
+    logits = lstm_logits_device(model, data, np.cumsum(lens), device=device)
+    out, k = [], 0
+    for n in lens:
+        out.append(logits[k:k + n])
+        k += n
+    return out

@@ -64,29 +64,69 @@ def split_segments(indices, data):
 # ------------------------------------------------------------------------------------------
 # stage: predict (logits producer)
 # ------------------------------------------------------------------------------------------
-def predict(model, audio_file, output_file, text_file, device=None, batch_size=128):
-    """MFCC segments -> per-segment logits, written as the reference writes them
-    (train.py:215-231: `*.logits.npz` via IndexDataArray, `*.greed.txt` lines
-    f'{index+1}|{merge_repeated(greedy decode)}').  Returns the logits [T_file, vocab] as ONE
-    device tensor (segments concatenated, like the file's `data`) so that the DP can take it by
-    pointer without re-reading the file."""
+def _write_logits(indices, logits, output_file, text_file):
+    """One file's *.logits.npz (IndexDataArray) and *.greed.txt as the reference writes them (train.py:215-231)."""
     import torch
-    from .model import segment_logits
-    device = device or next(model.parameters()).device
-    indices, data = read_index_data(audio_file)
-    seg_logits = segment_logits(model, split_segments(indices, data), device=device, batch_size=batch_size)
     try:
         with open_index_data_for_write(output_file) as out, open(text_file, 'wt') as txt:
-            for i, lg in enumerate(seg_logits):
-                greedy = torch.argmax(lg, dim=-1).cpu().numpy()
-                out.write(lg.detach().cpu().numpy().astype(np.float32))
-                txt.write(f'{i + 1}|{merge_repeated(decode_text(greedy))}\n')
+            start = 0
+            greedy_all = torch.argmax(logits, dim=-1).cpu().numpy()
+            host = logits.detach().cpu().numpy().astype(np.float32)
+            for i, end in enumerate(np.asarray(indices).tolist()):
+                out.write(host[start:end])
+                txt.write(f'{i + 1}|{merge_repeated(decode_text(greedy_all[start:end]))}\n')
+                start = end
     except BaseException:
         for f in (output_file, text_file):
             if os.path.exists(f):
                 os.unlink(f)
         raise
-    return torch.cat(seg_logits, dim=0) if seg_logits else torch.zeros((0, 0), device=device)
+
+
+def predict_files(model, audio_files, output_files, text_files, device=None):
+    """predict() for many files at once: the MFCC segments of ALL files go through the network together
+    (kokoro_align_amd.model.lstm_logits_device: a time step of the LSTM costs the same for 60 sequences or
+    4000), then every file's outputs are written in the reference's formats.  Returns {output_file: logits
+    [T_file, vocab] on the device}."""
+    import torch
+    from .model import lstm_logits_device
+    device = device or next(model.parameters()).device
+    datas, ends, per_file, base = [], [], [], 0
+    for af in audio_files:
+        indices, data = read_index_data(af)
+        rows = int(indices[-1]) if len(indices) else 0
+        datas.append(np.asarray(data[:rows], dtype=np.float32))
+        ends.append(np.asarray(indices, dtype=np.int64) + base)
+        per_file.append((np.asarray(indices, dtype=np.int64), base, rows))
+        base += rows
+    if not audio_files:
+        return {}
+    logits = lstm_logits_device(model, torch.from_numpy(np.concatenate(datas, axis=0)), np.concatenate(ends), device=device)
+    result = {}
+    for (indices, b, rows), of, tf in zip(per_file, output_files, text_files):
+        lg = logits[b:b + rows]
+        _write_logits(indices, lg, of, tf)
+        result[of] = lg
+    return result
+
+
+def predict(model, audio_file, output_file, text_file, device=None, batch_size=128):
+    """MFCC segments -> per-segment logits, written as the reference writes them
+    (train.py:215-231: `*.logits.npz` via IndexDataArray, `*.greed.txt` lines
+    f'{index+1}|{merge_repeated(greedy decode)}').  Returns the logits [T_file, vocab] as ONE
+    device tensor (segments concatenated, like the file's `data`) so that the DP can take it by
+    pointer without re-reading the file.  On a GPU the network runs through lstm_logits_device (all
+    segments at once); on the CPU through PyTorch, ``batch_size`` segments per call like the reference."""
+    import torch
+    from .model import segment_logits
+    device = torch.device(device) if device is not None else next(model.parameters()).device
+    if device.type == "cuda":
+        return predict_files(model, [audio_file], [output_file], [text_file], device=device)[output_file]
+    indices, data = read_index_data(audio_file)
+    seg_logits = segment_logits(model, split_segments(indices, data), device=device, batch_size=batch_size)
+    logits = torch.cat(seg_logits, dim=0) if seg_logits else torch.zeros((0, 0), device=device)
+    _write_logits(indices, logits, output_file, text_file)
+    return logits
 
 
 # ------------------------------------------------------------------------------------------
@@ -216,6 +256,7 @@ def process_alignment(dataset, audio_files, metadata_file, model=None, remove_wo
     bpath = _swap_ext(audio_files, '.mp3', '.best_path.npz')
     align_out = _swap_ext(audio_files, '.mp3', '.align.txt')
     on_device = {}
+    missing = []
     for mf, lf, gf in zip(mfcc, logits, greed):
         if os.path.exists(lf):
             say(f'Skip writing {lf}')
@@ -223,7 +264,15 @@ def process_alignment(dataset, audio_files, metadata_file, model=None, remove_wo
             if model is None:
                 raise ValueError(f'{lf} is missing and no model was given')
             say(f'Writing {lf}')
-            on_device[lf] = predict(model, mf, lf, gf, device=device)
+            missing.append((mf, lf, gf))
+    if missing:
+        import torch
+        dev = torch.device(device) if device is not None else next(model.parameters()).device
+        if dev.type == "cuda":     # every missing file through the network in one go
+            on_device = predict_files(model, [m[0] for m in missing], [m[1] for m in missing], [m[2] for m in missing], device=dev)
+        else:
+            for mf, lf, gf in missing:
+                on_device[lf] = predict(model, mf, lf, gf, device=dev)
     written = best_path_files(logits, voca, bpath, device=device, logits_on_device=on_device, host_softmax=host_softmax)
     for bf in bpath:
         say(f'Writing {bf}' if bf in written else f'Skip writing {bf}')

@@ -19,10 +19,12 @@ def test_audio_to_char_on_gpu_matches_reference(tmp_path):
     model.load_state_dict({k: torch.tensor(v, dtype=torch.float32) for k, v in a["state_dict"].items()})
     model = model.cuda().eval()
     segs = [O.hash_logprobs(n, 40, seed) + np.float32(4.0) for n, seed in zip(a["segment_lens"], a["segment_seeds"])]
-    got = segment_logits(model, segs)
-    for g, w in zip(got, a["logits"]):
-        assert g.is_cuda
-        assert np.allclose(g.cpu().numpy(), np.array(w, np.float32), atol=1e-4, rtol=0)   # MIOpen vs CPU LSTM
+    from kokoro_align_amd.model import segment_logits_device
+    for got in (segment_logits(model, segs),            # PyTorch-ROCm (MIOpen) vs the reference's CPU LSTM
+                segment_logits_device(model, segs)):    # library GEMMs + ka_lstm_step_f32 vs the same golden logits
+        for g, w in zip(got, a["logits"]):
+            assert g.is_cuda
+            assert np.allclose(g.cpu().numpy(), np.array(w, np.float32), atol=1e-4, rtol=0)
 
 
 def test_process_alignment_end_to_end(tmp_path):
@@ -69,3 +71,24 @@ def test_process_alignment_end_to_end(tmp_path):
     before = {f: os.path.getmtime(f) for f in [meta] + [a[:-4] + ".best_path.npz" for a in audio_files]}
     pipeline.process_alignment("ds", audio_files, meta, model=None, remove_wordsep=False, verbose=False)
     assert before == {f: os.path.getmtime(f) for f in before}
+
+
+@pytest.mark.gpu
+def test_device_lstm_matches_the_reference_network():
+    """segment_logits_device (library GEMMs + the fused HIP step kernel, all segments at once) against the
+    PyTorch CPU network of the reference's architecture (train.py:54-65) with the same weights: float32
+    rounding only (north-star tolerance 1e-4), ragged segment lengths, original order kept."""
+    import torch
+    from kokoro_align_amd.model import AudioToChar, segment_logits, segment_logits_device
+    torch.manual_seed(3)
+    rng = np.random.default_rng(3)
+    cpu = AudioToChar().eval()
+    segs = [rng.standard_normal((int(n), 40)).astype(np.float32) for n in [1, 7, 300, 64, 2, 129, 300, 511, 33]]
+    want = segment_logits(cpu, segs, device="cpu")
+    gpu = AudioToChar().eval()
+    gpu.load_state_dict(cpu.state_dict())
+    got = segment_logits_device(gpu.cuda(), segs)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g.shape == w.shape
+        np.testing.assert_allclose(g.cpu().numpy(), w.numpy(), rtol=0, atol=1e-4)
