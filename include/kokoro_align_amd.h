@@ -145,6 +145,17 @@ int ka_lstm_step_f32(const float *gin, int64_t ldg, const float *rec, int64_t re
                      int64_t state_dir_stride, float *out, int64_t ldo, const int32_t *rows, int64_t rows_dir_stride,
                      int32_t n, int32_t H, void *stream);
 
+/*
+ * One whole layer of the same LSTM (hidden size 128), both directions, every time step, in ONE persistent launch:
+ * a workgroup owns 32 sequences of one direction, the recurrent product runs on the float32 MFMA with its slice
+ * of W_hh register-resident, h in LDS.  Sequences must be sorted by length, longest first.
+ *   gin [frames, ldg >= 8H] as above; w_hh [2][4H][H] = weight_hh of the forward and the backward direction
+ *   (PyTorch layout, gate order i, f, g, o); out [frames, ldo >= 2H] = layer output (forward | backward);
+ *   seq_off / seq_len [nseq] int32 = first frame row and length of every sequence.  Device pointers.
+ */
+int ka_lstm_layer_f32(const float *gin, int64_t ldg, const float *w_hh, float *out, int64_t ldo, const int32_t *seq_off,
+                      const int32_t *seq_len, int32_t nseq, int32_t H, void *stream);
+
 /* Bit-reproducible synthetic inputs generated in HBM (same definition as the CPU oracle's
  * hash generator):  lp[t,c] = -8*u24(mix(seed, t*V+c)),
  * labels[k] = 1 + mix(seed^salt, k) % (V-1). */

@@ -29,6 +29,7 @@ EXPORTS = [
     "ka_ctc_best_path_batch_enqueue_f32", "ka_batch_finish", "ka_engine_set_profiling",
     "ka_engine_last_kernel_ms", "ka_log_softmax_f32", "ka_hash_logprobs_f32", "ka_hash_labels_i32",
     "ka_hash_logprobs_batch_f32", "ka_hash_labels_batch_i32", "ka_engine_set_mode", "ka_lstm_step_f32",
+    "ka_lstm_layer_f32",
 ]
 
 
@@ -93,6 +94,8 @@ def load_library():
     L.ka_engine_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     L.ka_log_softmax_f32.restype = ctypes.c_int
     L.ka_log_softmax_f32.argtypes = [vp, vp, i64, i32, i64, i64, vp]
+    L.ka_lstm_layer_f32.restype = ctypes.c_int
+    L.ka_lstm_layer_f32.argtypes = [vp, i64, vp, vp, i64, vp, vp, i32, i32, vp]
     L.ka_lstm_step_f32.restype = ctypes.c_int
     L.ka_lstm_step_f32.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, i64, vp, i64, i32, i32, vp]
     L.ka_hash_logprobs_f32.restype = ctypes.c_int

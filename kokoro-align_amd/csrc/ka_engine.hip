@@ -505,6 +505,19 @@ int ka_lstm_step_f32(const float *gin, int64_t ldg, const float *rec, int64_t re
     return KA_OK;
 }
 
+int ka_lstm_layer_f32(const float *gin, int64_t ldg, const float *w_hh, float *out, int64_t ldo, const int32_t *seq_off,
+                      const int32_t *seq_len, int32_t nseq, int32_t H, void *stream)
+{
+    if (!gin || !w_hh || !out || !seq_off || !seq_len || nseq < 0 || ldg < 8 * (int64_t)H || ldo < 2 * (int64_t)H)
+        return fail(KA_ERR_BAD_ARGS, "ka_lstm_layer_f32: bad arguments");
+    if (H != ka::kLstmH) return fail(KA_ERR_BAD_ARGS, "ka_lstm_layer_f32: the persistent kernel is built for hidden size 128");
+    if (nseq == 0) return KA_OK;
+    hipLaunchKernelGGL(ka::lstm_layer_kernel, dim3((unsigned)((nseq + 31) / 32), 2), dim3(256), 0, (hipStream_t)stream, gin, ldg, w_hh,
+                       out, ldo, seq_off, seq_len, nseq);
+    KA_HIP(hipGetLastError());
+    return KA_OK;
+}
+
 int ka_hash_logprobs_batch_f32(float *dev_log_probs, int32_t n, int64_t T, int32_t V, int64_t ld, int64_t lattice_stride,
                                uint64_t seed0, void *stream)
 {

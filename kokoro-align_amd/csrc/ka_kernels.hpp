@@ -1576,6 +1576,132 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------
+// One whole LSTM layer, both directions, persistent: a 256-thread workgroup owns 32 sequences of one direction
+// for ALL their time steps.  The recurrent product h @ W_hh^T runs on the f32 MFMA (v_mfma_f32_32x32x2_f32,
+// exact float32): wave w computes the four gates of hidden units [32w, 32w+32), and its 128 x 128 slice of
+// W_hh^T (64 KB) stays in registers for the whole kernel - 256 of the 512 VGPR/AGPRs a wave has at one
+// wave per SIMD - so no weight byte is read after start-up.  h lives in LDS (double-buffered, one barrier per
+// step); the input projections of a step are loaded before its MFMA loop and added after it.
+// Sequences are sorted by length (longest first): a tile runs for its first sequence's length.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_sigmoid(float x)
+{
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+}
+__device__ __forceinline__ float fast_tanh(float x)   // 1 - 2/(1 + e^{2x}): exact limits at +-inf
+{
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.88539008177792681472f));
+}
+constexpr int kLstmH = 128;
+constexpr int kLstmLdh = kLstmH + 4;   // LDS row pitch (floats): 16-byte aligned rows, conflict-free b128 A-fragment reads
+constexpr int kLstmWAcc = 60;          // k-steps of each gate whose W fragment lives in an AGPR (the other 4 in VGPRs)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// D = A*B + D with B taken straight from an accumulation register: the compiler's own allocation of the builtin
+// parked W in AGPRs and copied every fragment through one VGPR (v_accvgpr_read + s_nop + spill reloads) per MFMA.
+#define KA_MFMA_ACC(ACC, A, W) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "a"(W))
+#define KA_MFMA_VGPR(ACC, A, W) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(W))
+__global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const float *__restrict__ gin, int64_t ldg,
+                                                            const float *__restrict__ w_hh, float *__restrict__ out, int64_t ldo,
+                                                            const int32_t *__restrict__ seq_off, const int32_t *__restrict__ seq_len,
+                                                            int nseq)
+{
+    // h of the tile's 32 sequences, double-buffered; within a row unit k sits at (k&1)*64 + (k>>1), so the 64
+    // A operands of a lane (k = 2s + half, s = 0..63) are contiguous: 16 ds_read_b128 per step
+    __shared__ __attribute__((aligned(16))) float s_h[2][32][kLstmLdh];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int dir = blockIdx.y;
+    const int tile0 = blockIdx.x * 32;
+    const int col = lane & 31, half = lane >> 5;
+    const int jbase = 32 * wv;                       // hidden units of this wave
+    // W fragments: gate g, k-step s: B[k = 2s+half][n = col] = W_hh[dir][g*kLstmH + jbase + col][k]
+    float wreg[4][64];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int s = 0; s < 64; ++s)
+            wreg[g][s] = w_hh[((size_t)dir * 4 * kLstmH + (size_t)g * kLstmH + jbase + col) * kLstmH + 2 * s + half];
+    // the 16 sequences (rows of the C tile) this lane updates
+    int rowbase[16], len[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = tile0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int l = i < nseq ? seq_len[i] : 0;
+        const int o = i < nseq ? seq_off[i] : 0;
+        len[r] = l;
+        rowbase[r] = l <= 0 ? 0 : dir == 0 ? o : o + l - 1;   // empty / padding rows prefetch row 0 (never used)
+    }
+    const int tile_len = tile0 < nseq ? seq_len[tile0] : 0;   // sorted by length, longest first
+    float c[16], hreg[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = hreg[r] = 0.0f;
+    for (int i = tid; i < 2 * 32 * kLstmLdh; i += 256) (&s_h[0][0][0])[i] = 0.0f;
+    __syncthreads();
+    const float *gcol = gin + (size_t)dir * 4 * kLstmH + jbase + col;
+    float *ocol = out + (size_t)dir * kLstmH + jbase + col;
+    const int hpos = ((jbase + col) & 1) * 64 + ((jbase + col) >> 1);
+    // input projections one step ahead: they are the MFMA's initial accumulator, so they must have landed
+    // before the step starts; a finished sequence re-reads its last row (never used)
+    auto gin_row = [&](int r, int t) {
+        const int k = max(min(t, len[r] - 1), 0);
+        return gcol + (size_t)(dir == 0 ? rowbase[r] + k : rowbase[r] - k) * (size_t)ldg;
+    };
+    f32x16 nxt[4];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float *gp = gin_row(r, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) nxt[g][r] = gp[(size_t)g * kLstmH];
+    }
+    for (int t = 0; t < tile_len; ++t) {
+        const int cur = t & 1;
+        f32x16 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = nxt[g];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float *gp = gin_row(r, t + 1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) nxt[g][r] = gp[(size_t)g * kLstmH];
+        }
+        const f32x4 *arow = reinterpret_cast<const f32x4 *>(&s_h[cur][col][half * 64]);
+        asm volatile("s_nop 3" ::: "memory");   // VALU-written accumulators -> first MFMA
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const f32x4 a4 = arow[q];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int s = 4 * q + u;
+                const float a = a4[u];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (s < kLstmWAcc) KA_MFMA_ACC(acc[g], a, wreg[g][s]);
+                    else KA_MFMA_VGPR(acc[g], a, wreg[g][s]);
+                }
+            }
+        }
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // 16-pass MFMA result -> VALU read: 18 wait states
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const bool act = t < len[r];
+            // hardware exp2 / rcp (about 1 ulp each): 4 instructions per sigmoid instead of a ~40-instruction libm call
+            const float si = fast_sigmoid(acc[0][r]), sf = fast_sigmoid(acc[1][r]), so = fast_sigmoid(acc[3][r]);
+            const float cn = sf * c[r] + si * fast_tanh(acc[2][r]);
+            const float hn = so * fast_tanh(cn);
+            if (act) {
+                c[r] = cn;
+                hreg[r] = hn;
+                ocol[(size_t)(dir == 0 ? rowbase[r] + t : rowbase[r] - t) * (size_t)ldo] = hn;
+            }
+            s_h[cur ^ 1][i][hpos] = hreg[r];
+        }
+        __syncthreads();
+    }
+}
+#undef KA_MFMA_ACC
+#undef KA_MFMA_VGPR
+
+// ---------------------------------------------------------------------------------------
 // hash generator of synthetic inputs (definition: include/kokoro_align_amd.h)
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t idx)

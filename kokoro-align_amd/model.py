@@ -52,7 +52,7 @@ def segment_logits(model, segments, device=None, batch_size=128):
 
 
 @torch.no_grad()
-def lstm_logits_device(model, data, indices, device=None):
+def lstm_logits_device(model, data, indices, device=None, persistent=True):
     """Logits of every frame of an IndexDataArray (``data`` [rows, n_mfcc], ``indices`` = cumulative segment ends,
     kokoro_align/preprocess.py:12-35), [rows, vocab] on ``device`` in the file's row order - what the reference's
     predict() writes to *.logits.npz (train.py:215-231) - computed for ALL segments at once.
@@ -93,12 +93,15 @@ def lstm_logits_device(model, data, indices, device=None):
     n_run = (n - np.searchsorted(slen[::-1], np.arange(max_len), side="right")).tolist()
     d_offs = torch.from_numpy(offs).to(device)
     d_len = torch.from_numpy(slen).to(device)
-    steps = torch.arange(max_len, dtype=torch.int64, device=device).unsqueeze(1)
-    rows = torch.stack([d_offs.unsqueeze(0) + steps, d_offs.unsqueeze(0) + d_len.unsqueeze(0) - 1 - steps], 0)   # [2, max_len, n]
-    rows = rows.clamp_(0, total - 1).to(torch.int32).contiguous()
-    rows_ptr, rows_step, rows_dir = rows.data_ptr(), n * 4, rows.stride(0)
-    stream = torch.cuda.current_stream(device).cuda_stream
+    d_offs32, d_len32 = d_offs.to(torch.int32), d_len.to(torch.int32)
     H = model.hidden_dim
+    persistent = persistent and H == 128
+    if not persistent:
+        steps = torch.arange(max_len, dtype=torch.int64, device=device).unsqueeze(1)
+        rows = torch.stack([d_offs.unsqueeze(0) + steps, d_offs.unsqueeze(0) + d_len.unsqueeze(0) - 1 - steps], 0)   # [2, max_len, n]
+        rows = rows.clamp_(0, total - 1).to(torch.int32).contiguous()
+        rows_ptr, rows_step, rows_dir = rows.data_ptr(), n * 4, rows.stride(0)
+    stream = torch.cuda.current_stream(device).cuda_stream
     sd = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in model.state_dict().items()}
     inp = x
     for layer in range(model.lstm.num_layers):
@@ -108,6 +111,14 @@ def lstm_logits_device(model, data, indices, device=None):
         w_hh_t = torch.stack([sd["lstm.weight_hh" + s].t().contiguous() for s in sfx], 0)  # [2, H, 4H]
         gin = torch.addmm(bias, inp, w_ih.t())                                             # [total, 8H]
         out = torch.empty((total, 2 * H), dtype=torch.float32, device=device)
+        if persistent:
+            # the whole layer in one launch: ka_lstm_layer_f32 (f32 MFMA, W_hh register-resident, h in LDS)
+            w_hh = torch.stack([sd["lstm.weight_hh" + s] for s in sfx], 0).contiguous()      # [2, 4H, H]
+            _lib.check(lib.ka_lstm_layer_f32(gin.data_ptr(), gin.stride(0), w_hh.data_ptr(), out.data_ptr(), out.stride(0),
+                                             d_offs32.data_ptr(), d_len32.data_ptr(), n, H, stream), "ka_lstm_layer_f32")
+            del gin
+            inp = out
+            continue
         h = torch.zeros((2, n, H), dtype=torch.float32, device=device)
         c = torch.zeros((2, n, H), dtype=torch.float32, device=device)
         rec = torch.empty((2, n, 4 * H), dtype=torch.float32, device=device)
