@@ -512,7 +512,7 @@ int ka_lstm_layer_f32(const float *gin, int64_t ldg, const float *w_hh, float *o
         return fail(KA_ERR_BAD_ARGS, "ka_lstm_layer_f32: bad arguments");
     if (H != ka::kLstmH) return fail(KA_ERR_BAD_ARGS, "ka_lstm_layer_f32: the persistent kernel is built for hidden size 128");
     if (nseq == 0) return KA_OK;
-    hipLaunchKernelGGL(ka::lstm_layer_kernel, dim3((unsigned)((nseq + 31) / 32), 2), dim3(256), 0, (hipStream_t)stream, gin, ldg, w_hh,
+    hipLaunchKernelGGL(ka::lstm_layer_kernel, dim3(2u * (unsigned)((nseq + ka::kLstmTile - 1) / ka::kLstmTile)), dim3(256), 0, (hipStream_t)stream, gin, ldg, w_hh,
                        out, ldo, seq_off, seq_len, nseq);
     KA_HIP(hipGetLastError());
     return KA_OK;

@@ -1593,108 +1593,125 @@ __device__ __forceinline__ float fast_tanh(float x)   // 1 - 2/(1 + e^{2x}): exa
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.88539008177792681472f));
 }
 constexpr int kLstmH = 128;
+constexpr int kLstmTile = 16;          // sequences per workgroup
 constexpr int kLstmLdh = kLstmH + 4;   // LDS row pitch (floats): 16-byte aligned rows, conflict-free b128 A-fragment reads
-constexpr int kLstmWAcc = 60;          // k-steps of each gate whose W fragment lives in an AGPR (the other 4 in VGPRs)
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kLstmWAcc = 30;          // k-steps whose 8 W fragments live in AGPRs (240 of 256); the last two sit in VGPRs
 // D = A*B + D with B taken straight from an accumulation register: the compiler's own allocation of the builtin
 // parked W in AGPRs and copied every fragment through one VGPR (v_accvgpr_read + s_nop + spill reloads) per MFMA.
-#define KA_MFMA_ACC(ACC, A, W) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "a"(W))
-#define KA_MFMA_VGPR(ACC, A, W) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(W))
+#define KA_MFMA_ACC(ACC, A, W) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "a"(W))
+#define KA_MFMA_VGPR(ACC, A, W) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(W))
+// grid.x = 2 * ceil(nseq / 16): workgroup id>>1 = tile (longest sequences first, so the dispatcher starts the
+// long tiles first and back-fills the CUs with short ones), id&1 = direction
 __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const float *__restrict__ gin, int64_t ldg,
                                                             const float *__restrict__ w_hh, float *__restrict__ out, int64_t ldo,
                                                             const int32_t *__restrict__ seq_off, const int32_t *__restrict__ seq_len,
                                                             int nseq)
 {
-    // h of the tile's 32 sequences, double-buffered; within a row unit k sits at (k&1)*64 + (k>>1), so the 64
-    // A operands of a lane (k = 2s + half, s = 0..63) are contiguous: 16 ds_read_b128 per step
-    __shared__ __attribute__((aligned(16))) float s_h[2][32][kLstmLdh];
+    // h of the tile's 16 sequences, double-buffered; within a row unit k sits at (k&3)*32 + (k>>2), so the 32
+    // A operands of a lane (k = 4s + kq, s = 0..31) are contiguous: 8 ds_read_b128 per step
+    __shared__ __attribute__((aligned(16))) float s_h[2][kLstmTile][kLstmLdh];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int dir = blockIdx.y;
-    const int tile0 = blockIdx.x * 32;
-    const int col = lane & 31, half = lane >> 5;
-    const int jbase = 32 * wv;                       // hidden units of this wave
-    // W fragments: gate g, k-step s: B[k = 2s+half][n = col] = W_hh[dir][g*kLstmH + jbase + col][k]
-    float wreg[4][64];
+    const int dir = blockIdx.x & 1;
+    const int tile0 = (blockIdx.x >> 1) * kLstmTile;
+    const int col = lane & 15, kq = lane >> 4;
+    const int jbase = 32 * wv;                       // hidden units of this wave: two column tiles of 16
+    // W fragments: gate g, column tile ct, k-step s: B[k = 4s+kq][n = col] = W_hh[dir][g*H + jbase + 16ct + col][k]
+    float wreg[4][2][32];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int s = 0; s < 64; ++s)
-            wreg[g][s] = w_hh[((size_t)dir * 4 * kLstmH + (size_t)g * kLstmH + jbase + col) * kLstmH + 2 * s + half];
-    // the 16 sequences (rows of the C tile) this lane updates
-    int rowbase[16], len[16];
+        for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int i = tile0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            for (int s = 0; s < 32; ++s)
+                wreg[g][ct][s] = w_hh[((size_t)dir * 4 * kLstmH + (size_t)g * kLstmH + jbase + 16 * ct + col) * kLstmH + 4 * s + kq];
+    // the 4 sequences (rows 4kq .. 4kq+3 of the C tile) this lane updates
+    int rowbase[4], len[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = tile0 + 4 * kq + r;
         const int l = i < nseq ? seq_len[i] : 0;
         const int o = i < nseq ? seq_off[i] : 0;
         len[r] = l;
         rowbase[r] = l <= 0 ? 0 : dir == 0 ? o : o + l - 1;   // empty / padding rows prefetch row 0 (never used)
     }
     const int tile_len = tile0 < nseq ? seq_len[tile0] : 0;   // sorted by length, longest first
-    float c[16], hreg[16];
+    float c[2][4], hreg[2][4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) c[r] = hreg[r] = 0.0f;
-    for (int i = tid; i < 2 * 32 * kLstmLdh; i += 256) (&s_h[0][0][0])[i] = 0.0f;
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[ct][r] = hreg[ct][r] = 0.0f;
+    for (int i = tid; i < 2 * kLstmTile * kLstmLdh; i += 256) (&s_h[0][0][0])[i] = 0.0f;
     __syncthreads();
     const float *gcol = gin + (size_t)dir * 4 * kLstmH + jbase + col;
     float *ocol = out + (size_t)dir * kLstmH + jbase + col;
-    const int hpos = ((jbase + col) & 1) * 64 + ((jbase + col) >> 1);
+    int hpos[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) hpos[ct] = ((jbase + 16 * ct + col) & 3) * 32 + ((jbase + 16 * ct + col) >> 2);
     // input projections one step ahead: they are the MFMA's initial accumulator, so they must have landed
     // before the step starts; a finished sequence re-reads its last row (never used)
     auto gin_row = [&](int r, int t) {
         const int k = max(min(t, len[r] - 1), 0);
         return gcol + (size_t)(dir == 0 ? rowbase[r] + k : rowbase[r] - k) * (size_t)ldg;
     };
-    f32x16 nxt[4];
+    f32x4 nxt[4][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < 4; ++r) {
         const float *gp = gin_row(r, 0);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) nxt[g][r] = gp[(size_t)g * kLstmH];
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) nxt[g][ct][r] = gp[(size_t)g * kLstmH + 16 * ct];
     }
     for (int t = 0; t < tile_len; ++t) {
         const int cur = t & 1;
-        f32x16 acc[4];
+        f32x4 acc[4][2];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = nxt[g];
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+            for (int ct = 0; ct < 2; ++ct) acc[g][ct] = nxt[g][ct];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
             const float *gp = gin_row(r, t + 1);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) nxt[g][r] = gp[(size_t)g * kLstmH];
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) nxt[g][ct][r] = gp[(size_t)g * kLstmH + 16 * ct];
         }
-        const f32x4 *arow = reinterpret_cast<const f32x4 *>(&s_h[cur][col][half * 64]);
+        const f32x4 *arow = reinterpret_cast<const f32x4 *>(&s_h[cur][col][kq * 32]);
         asm volatile("s_nop 3" ::: "memory");   // VALU-written accumulators -> first MFMA
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
+        for (int q = 0; q < 8; ++q) {
             const f32x4 a4 = arow[q];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int s = 4 * q + u;
                 const float a = a4[u];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if (s < kLstmWAcc) KA_MFMA_ACC(acc[g], a, wreg[g][s]);
-                    else KA_MFMA_VGPR(acc[g], a, wreg[g][s]);
-                }
-            }
-        }
-        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // 16-pass MFMA result -> VALU read: 18 wait states
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const bool act = t < len[r];
-            // hardware exp2 / rcp (about 1 ulp each): 4 instructions per sigmoid instead of a ~40-instruction libm call
-            const float si = fast_sigmoid(acc[0][r]), sf = fast_sigmoid(acc[1][r]), so = fast_sigmoid(acc[3][r]);
-            const float cn = sf * c[r] + si * fast_tanh(acc[2][r]);
-            const float hn = so * fast_tanh(cn);
-            if (act) {
-                c[r] = cn;
-                hreg[r] = hn;
-                ocol[(size_t)(dir == 0 ? rowbase[r] + t : rowbase[r] - t) * (size_t)ldo] = hn;
+                    for (int ct = 0; ct < 2; ++ct) {
+                        if (s < kLstmWAcc) KA_MFMA_ACC(acc[g][ct], a, wreg[g][ct][s]);
+                        else KA_MFMA_VGPR(acc[g][ct], a, wreg[g][ct][s]);
+                    }
             }
-            s_h[cur ^ 1][i][hpos] = hreg[r];
         }
+        asm volatile("s_nop 10" ::: "memory");   // 8-pass MFMA result -> VALU read: 11 wait states
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool act = t < len[r];
+                // hardware exp2 / rcp (about 1 ulp each): 4 instructions per sigmoid instead of a ~40-instruction libm call
+                const float si = fast_sigmoid(acc[0][ct][r]), sf = fast_sigmoid(acc[1][ct][r]), so = fast_sigmoid(acc[3][ct][r]);
+                const float cn = sf * c[ct][r] + si * fast_tanh(acc[2][ct][r]);
+                const float hn = so * fast_tanh(cn);
+                if (act) {
+                    c[ct][r] = cn;
+                    hreg[ct][r] = hn;
+                    ocol[(size_t)(dir == 0 ? rowbase[r] + t : rowbase[r] - t) * (size_t)ldo + 16 * ct] = hn;
+                }
+                s_h[cur ^ 1][4 * kq + r][hpos[ct]] = hreg[ct][r];
+            }
         __syncthreads();
     }
 }

@@ -60,10 +60,11 @@ def lstm_logits_device(model, data, indices, device=None, persistent=True):
     The reference runs the network file by file, 128 segments per call; MIOpen's LSTM then spends ~100 us per
     time step whatever the batch, and refuses large batches.  Here every layer is
       * one library GEMM for the input projections of all frames of all segments (x @ W_ih^T + b_ih + b_hh),
-      * per time step ONE batched library GEMM (h @ W_hh^T, both directions) and ONE fused HIP kernel
-        (ka_lstm_step_f32: gate non-linearities, cell update, scatter of h into the layer output),
-    with the segments sorted by length so that the sequences still running are a prefix.  Inference only (no
-    dropout); float32; equal to the PyTorch network within rounding (tests: 1e-4).
+      * then ONE launch of the persistent HIP kernel ka_lstm_layer_f32 (``persistent``, hidden size 128: a
+        workgroup carries 32 sequences through all their steps, h @ W_hh^T on the f32 MFMA with W_hh resident in
+        registers), or per time step one batched library GEMM + the fused cell kernel ka_lstm_step_f32,
+    with the segments sorted by length.  Inference only (no dropout); float32; equal to the PyTorch network
+    within rounding (tests: 1e-4).
     """
     import numpy as np
     from . import _lib
@@ -83,20 +84,26 @@ def lstm_logits_device(model, data, indices, device=None, persistent=True):
     order = keep[np.argsort(-lens[keep], kind="stable")]
     n = int(order.size)
     slen = lens[order]
-    offs = np.concatenate([[0], np.cumsum(slen)[:-1]])  # row offsets in the length-sorted layout
     max_len = int(slen[0])
-    # sorted row r of segment i (sorted position s): file row starts[order[s]] + (r - offs[s])
-    seg_of_row = np.repeat(np.arange(n), slen)
-    perm = torch.from_numpy((starts[order][seg_of_row] + (np.arange(total) - offs[seg_of_row])).astype(np.int64)).to(device)
-    x = x_file.index_select(0, perm)
-    # sequences still running at step t (lengths are sorted descending), frame rows of every (direction, step, sequence)
-    n_run = (n - np.searchsorted(slen[::-1], np.arange(max_len), side="right")).tolist()
-    d_offs = torch.from_numpy(offs).to(device)
-    d_len = torch.from_numpy(slen).to(device)
-    d_offs32, d_len32 = d_offs.to(torch.int32), d_len.to(torch.int32)
     H = model.hidden_dim
     persistent = persistent and H == 128
+    if persistent:
+        # the persistent kernel addresses each sequence by (first row, length): the frames stay in the file's
+        # row order, only the small per-segment tables are sorted (a tile of 32 runs for its longest member)
+        offs = starts[order]
+        x, perm = x_file, None
+    else:
+        offs = np.concatenate([[0], np.cumsum(slen)[:-1]])  # row offsets in the length-sorted layout
+        # sorted row r of segment i (sorted position s): file row starts[order[s]] + (r - offs[s])
+        seg_of_row = np.repeat(np.arange(n), slen)
+        perm = torch.from_numpy((starts[order][seg_of_row] + (np.arange(total) - offs[seg_of_row])).astype(np.int64)).to(device)
+        x = x_file.index_select(0, perm)
+    d_offs = torch.from_numpy(np.ascontiguousarray(offs)).to(device)
+    d_len = torch.from_numpy(np.ascontiguousarray(slen)).to(device)
+    d_offs32, d_len32 = d_offs.to(torch.int32), d_len.to(torch.int32)
     if not persistent:
+        # sequences still running at step t (lengths are sorted descending), frame rows of every (direction, step, sequence)
+        n_run = (n - np.searchsorted(slen[::-1], np.arange(max_len), side="right")).tolist()
         steps = torch.arange(max_len, dtype=torch.int64, device=device).unsqueeze(1)
         rows = torch.stack([d_offs.unsqueeze(0) + steps, d_offs.unsqueeze(0) + d_len.unsqueeze(0) - 1 - steps], 0)   # [2, max_len, n]
         rows = rows.clamp_(0, total - 1).to(torch.int32).contiguous()
@@ -135,13 +142,15 @@ def lstm_logits_device(model, data, indices, device=None, persistent=True):
         del gin
         inp = out
     logits_sorted = torch.addmm(sd["dense.bias"], inp, sd["dense.weight"].t())
+    if perm is None:
+        return logits_sorted
     logits = torch.empty_like(logits_sorted)
     logits.index_copy_(0, perm, logits_sorted)           # back to the file's row order
     return logits
 
 
 @torch.no_grad()
-def segment_logits_device(model, segments, device=None):
+def segment_logits_device(model, segments, device=None, persistent=True):
     """``segment_logits`` through ``lstm_logits_device``: list of [len_i, n_mfcc] -> list of [len_i, vocab] on the
     device, in the order given."""
     import numpy as np
@@ -149,7 +158,7 @@ def segment_logits_device(model, segments, device=None):
         return []
     lens = [int(s.shape[0]) for s in segments]
     data = torch.cat([torch.as_tensor(s, dtype=torch.float32) for s in segments], dim=0)
-    logits = lstm_logits_device(model, data, np.cumsum(lens), device=device)
+    logits = lstm_logits_device(model, data, np.cumsum(lens), device=device, persistent=persistent)
     out, k = [], 0
     for n in lens:
         out.append(logits[k:k + n])

@@ -21,7 +21,8 @@ def test_audio_to_char_on_gpu_matches_reference(tmp_path):
     segs = [O.hash_logprobs(n, 40, seed) + np.float32(4.0) for n, seed in zip(a["segment_lens"], a["segment_seeds"])]
     from kokoro_align_amd.model import segment_logits_device
     for got in (segment_logits(model, segs),            # PyTorch-ROCm (MIOpen) vs the reference's CPU LSTM
-                segment_logits_device(model, segs)):    # library GEMMs + ka_lstm_step_f32 vs the same golden logits
+                segment_logits_device(model, segs),     # library GEMMs + ka_lstm_layer_f32 vs the same golden logits
+                segment_logits_device(model, segs, persistent=False)):   # ... + per-step GEMM and ka_lstm_step_f32
         for g, w in zip(got, a["logits"]):
             assert g.is_cuda
             assert np.allclose(g.cpu().numpy(), np.array(w, np.float32), atol=1e-4, rtol=0)
@@ -87,8 +88,29 @@ def test_device_lstm_matches_the_reference_network():
     want = segment_logits(cpu, segs, device="cpu")
     gpu = AudioToChar().eval()
     gpu.load_state_dict(cpu.state_dict())
-    got = segment_logits_device(gpu.cuda(), segs)
-    assert len(got) == len(want)
-    for g, w in zip(got, want):
-        assert g.shape == w.shape
-        np.testing.assert_allclose(g.cpu().numpy(), w.numpy(), rtol=0, atol=1e-4)
+    gpu = gpu.cuda()
+    for persistent in (True, False):
+        got = segment_logits_device(gpu, segs, persistent=persistent)
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert g.shape == w.shape
+            np.testing.assert_allclose(g.cpu().numpy(), w.numpy(), rtol=0, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_persistent_lstm_many_tiles_and_empty_segments():
+    """More sequences than one 32-row tile, lengths that straddle tile boundaries, empty segments in the index
+    table (they own no rows), against the per-step device path (itself checked against the CPU network above)."""
+    import torch
+    from kokoro_align_amd.model import AudioToChar, lstm_logits_device
+    torch.manual_seed(11)
+    rng = np.random.default_rng(11)
+    model = AudioToChar().cuda().eval()
+    lens = rng.integers(0, 90, size=150)
+    lens[[0, 17, 149]] = 0
+    lens[40] = 257
+    data = rng.standard_normal((int(lens.sum()) + 5, 40)).astype(np.float32)   # rows past the last index are ignored
+    a = lstm_logits_device(model, data, np.cumsum(lens), persistent=True)
+    b = lstm_logits_device(model, data, np.cumsum(lens), persistent=False)
+    assert a.shape == b.shape == (int(lens.sum()), 39)
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=1e-4)
