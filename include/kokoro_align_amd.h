@@ -147,8 +147,10 @@ int ka_lstm_step_f32(const float *gin, int64_t ldg, const float *rec, int64_t re
 
 /*
  * One whole layer of the same LSTM (hidden size 128), both directions, every time step, in ONE persistent launch:
- * a workgroup owns 32 sequences of one direction, the recurrent product runs on the float32 MFMA with its slice
- * of W_hh register-resident, h in LDS.  Sequences must be sorted by length, longest first.
+ * a workgroup owns 16 sequences of one direction, the recurrent product runs on the float32 MFMA with its slice
+ * of W_hh register-resident, h in LDS.  Sequences must be sorted by length, longest first; they may lie anywhere
+ * in gin / out (frames need not be reordered); gin must hold at least one row.  sigmoid/tanh use the hardware
+ * exp2 and reciprocal (about 1 ulp each).
  *   gin [frames, ldg >= 8H] as above; w_hh [2][4H][H] = weight_hh of the forward and the backward direction
  *   (PyTorch layout, gate order i, f, g, o); out [frames, ldo >= 2H] = layer output (forward | backward);
  *   seq_off / seq_len [nseq] int32 = first frame row and length of every sequence.  Device pointers.

@@ -2,7 +2,7 @@
 """Stage times of the device-resident pipeline around the hot path on a synthetic
 book: MFCC segments -> AudioToChar (PyTorch-ROCm / MIOpen LSTM) -> HIP log-softmax -> batched CTC best path.
 
-    python tools/bench_pipeline.py [chapters] [frames_per_chapter] [segments_per_lstm_call] [across|device]
+    python tools/bench_pipeline.py [chapters] [frames_per_chapter] [segments_per_lstm_call] [across|device|device_steps]
 
 Random-init network of the reference's architecture (train.py:54-65), random MFCC-shaped input cut into
 segments of 200-1200 frames like the reference's splitter produces, labels = S ~ 0.14*T phonemes per chapter.
@@ -25,7 +25,8 @@ chapters = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 43000
 BATCH = int(sys.argv[3]) if len(sys.argv) > 3 else 128      # segments per LSTM call (the reference uses 128)
 ACROSS = len(sys.argv) > 4 and sys.argv[4] == "across"     # batch the segments of all chapters together (MIOpen)
-DEVICE_LSTM = len(sys.argv) > 4 and sys.argv[4] == "device"   # kokoro_align_amd.model.segment_logits_device
+DEVICE_LSTM = len(sys.argv) > 4 and sys.argv[4] in ("device", "device_steps")   # kokoro_align_amd.model.lstm_logits_device
+PERSISTENT = len(sys.argv) > 4 and sys.argv[4] == "device"   # ka_lstm_layer_f32 (one launch per layer) vs one GEMM + ka_lstm_step_f32 per step
 dev = torch.device("cuda", 0)
 rng = np.random.default_rng(0)
 torch.manual_seed(0)
@@ -53,8 +54,8 @@ book_ends = np.cumsum([int(s.shape[0]) for _, segs, _ in books for s in segs])
 times = {}
 for rep in range(2):      # second pass is the measured one (MIOpen find, allocator warm-up)
     sync(); t0 = time.perf_counter()
-    if DEVICE_LSTM:   # library GEMMs + fused HIP step kernel, every segment of the book at once
-        all_logits = lstm_logits_device(model, book_data, book_ends, device=dev)
+    if DEVICE_LSTM:   # library GEMMs + HIP recurrence kernels, every segment of the book at once
+        all_logits = lstm_logits_device(model, book_data, book_ends, device=dev, persistent=PERSISTENT)
         logits, k = [], 0
         for T, _, _ in books:
             logits.append(all_logits[k:k + T])
@@ -76,6 +77,6 @@ for rep in range(2):      # second pass is the measured one (MIOpen find, alloca
     times = {"acoustic_model_ms": (t1 - t0) * 1e3, "log_softmax_ms": (t2 - t1) * 1e3, "ctc_best_path_ms": (t3 - t2) * 1e3}
 total_frames = sum(T for T, _, _ in books)
 ends_ok = all(int(p[-1]) == 2 * len(lab) for (p, _, _), (_, _, lab) in zip(res, books))
-print(json.dumps({"segments_per_lstm_call": BATCH, "acoustic_model": "device_lstm" if DEVICE_LSTM else ("miopen_across_chapters" if ACROSS else "miopen_per_chapter"), "chapters": chapters, "frames": total_frames, "audio_hours": total_frames * 0.0116 / 3600, "vocab": V,
+print(json.dumps({"segments_per_lstm_call": BATCH, "acoustic_model": ("device_lstm_persistent" if PERSISTENT else "device_lstm_steps") if DEVICE_LSTM else ("miopen_across_chapters" if ACROSS else "miopen_per_chapter"), "chapters": chapters, "frames": total_frames, "audio_hours": total_frames * 0.0116 / 3600, "vocab": V,
                   **times, "frames_per_s_end_to_end": total_frames / (sum(times.values()) * 1e-3),
                   "all_paths_end_at_the_trailing_blank": bool(ends_ok)}))
