@@ -467,6 +467,57 @@ __device__ __forceinline__ float cell_label_score(float a0, float a1, float a2, 
     return __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), a2), a3) + e;
 }
 
+// The same without the emission (added two cells at a time by frame_scores)
+template <int M>
+__device__ __forceinline__ float cell_blank_max(float a0, float a1, float a3)
+{
+    if constexpr (M == 1) return a0;
+    if constexpr (M <= 3) return __builtin_fmaxf(a0, a1);
+    return __builtin_fmaxf(__builtin_fmaxf(a0, a1), a3);
+}
+template <int M, bool ZL>
+__device__ __forceinline__ float cell_label_max(float a0, float a1, float a2, float a3, float veto)
+{
+    if constexpr (M == 1) return a0;
+    if constexpr (M == 2) return __builtin_fmaxf(a0, a1);
+    if constexpr (ZL) a2 = __builtin_fminf(a2, veto);   // veto = -inf where the label value is 0 (move 2 not allowed), else +inf
+    if constexpr (M == 3) return __builtin_fmaxf(__builtin_fmaxf(a0, a1), a2);
+    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), a2), a3);
+}
+// Score registers of the checkpointed kernel: cell k of a lane sits in P[2*(k>>2) + (k&1)][(k>>1)&1], i.e. the
+// two blank cells of a group of four share one 64-bit register pair and so do its two label cells - the emission
+// is then added to two cells per instruction (v_pk_add_f32: the vector ALU is what bounds this kernel).
+#define KA_P(P, k) (P)[2 * ((k) >> 2) + ((k) & 1)][((k) >> 1) & 1]
+// cells 4G+3..4G of one frame, in place (descending G: cell k reads the old k-1..k-3), NO band mask
+template <int M, bool ZL, int G>
+__device__ __forceinline__ void frame_scores(f32x2 (&P)[8], float h1, float h2, float h3, f32x2 (&E)[4], const float (&vz)[8],
+                                             f32x2 e00, const int (&la)[8], float next_row)
+{
+    const float b0 = P[2 * G][0], l0 = P[2 * G + 1][0], b1 = P[2 * G][1], l1 = P[2 * G + 1][1];
+    const float p1 = G > 0 ? P[2 * (G > 0 ? G - 1 : 0) + 1][1] : h1;   // cell 4G-1 (label)
+    const float p2 = G > 0 ? P[2 * (G > 0 ? G - 1 : 0)][1] : h2;       // cell 4G-2 (blank)
+    const float p3 = G > 0 ? P[2 * (G > 0 ? G - 1 : 0) + 1][0] : h3;   // cell 4G-3 (label)
+    f32x2 ml, mb;
+    ml[1] = cell_label_max<M, ZL>(l1, b1, l0, b0, vz[2 * G + 1]);
+    mb[1] = cell_blank_max<M>(b1, l0, p1);
+    ml[0] = cell_label_max<M, ZL>(l0, b0, p1, p2, vz[2 * G]);
+    mb[0] = cell_blank_max<M>(b0, p1, p3);
+    P[2 * G + 1] = ml + E[G];
+    P[2 * G] = mb + e00;
+    E[G][0] = bperm(la[2 * G], next_row);
+    E[G][1] = bperm(la[2 * G + 1], next_row);
+    __builtin_amdgcn_sched_barrier(0);   // as in frame_cells: keep the groups in program order
+    if constexpr (G > 0) frame_scores<M, ZL, G - 1>(P, h1, h2, h3, E, vz, e00, la, next_row);
+}
+
+// -inf into the cells outside the band
+template <int K>
+__device__ __forceinline__ void mask_scores(f32x2 (&P)[8], BandMasks &mk, float NINF)
+{
+    KA_P(P, K) = select_by_mask(NINF, KA_P(P, K), mk.at<K>());
+    if constexpr (K > 0) mask_scores<K - 1>(P, mk, NINF);
+}
+
 // cells 15..0 of one frame, in place (descending k: cell k reads the old k-1..k-3)
 // The emission register of a label cell is refilled for the NEXT frame (ds_bpermute of the next
 // row) right after the cell has consumed it: one set of 8 emission registers, and a whole frame of
@@ -517,10 +568,14 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
     const uint32_t dq = L / T, dr = L % T;
     const float NINF = ninf();
 
-    float sc[16];
+    float sc[16];                           // exact kernel: one register per cell
+    f32x2 P[8];                             // checkpointed kernel: the same cells in pairs (see KA_P)
 #pragma unroll
     for (int k = 0; k < 16; ++k) sc[k] = NINF;
     if (lane == 0) sc[0] = 0.0f;            // virtual state before frame 0 (align.py:57-58)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) KA_P(P, k) = sc[k];
+    uint32_t mask_frames = 0;               // wave-uniform: frames (this one included) that must apply the band mask
     uint32_t pres2 = lane == 0 ? 1u : 0u;   // bit 2k: cell k holds a live state
     float absum = 0.0f;                     // LITE: sum over frames of |lp[t, lane]| (finiteness check)
     bool pend_reset = false;                // wave-uniform: some lane was re-labelled for this frame
@@ -558,8 +613,11 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
     // emissions of the label cells: e[i] holds frame t's value until cell 2i+1 has used it, then
     // frame t+1's (see frame_cells); the blank emission is a scalar, double-buffered by frame parity
     float e[8], e0[2];
+    f32x2 E[4];
 #pragma unroll
     for (int i = 0; i < 8; ++i) e[i] = bperm(la[i], rows[0]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) E[i >> 1][i & 1] = e[i];
     e0[0] = first_lane(rows[0]);
     if constexpr (LITE) absum = __builtin_fabsf(rows[0]);
 
@@ -582,7 +640,8 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                 // Halos of frame t, then the reset of lanes re-labelled in frame t-1 (they still held the scores of
                 // their OLD block, which their right neighbour has just read as its halo).  Done before step A so that
                 // A can write the flags of the NEXT frame in place (no per-frame copies of flags and band limits).
-                float h1 = wave_ror1(sc[15]), h2 = wave_ror1(sc[14]), h3 = wave_ror1(sc[13]);
+                float h1 = wave_ror1(LITE ? KA_P(P, 15) : sc[15]), h2 = wave_ror1(LITE ? KA_P(P, 14) : sc[14]),
+                      h3 = wave_ror1(LITE ? KA_P(P, 13) : sc[13]);
                 if (__builtin_expect(pend_reset, 0)) {
                     asm volatile("" ::: "memory");  // keep this rare block a real branch (no if-conversion)
                     // a lane re-labelled for this frame holds scores of its OLD block: its new
@@ -594,7 +653,10 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                     h2 = kill ? NINF : h2;
                     h3 = kill ? NINF : h3;
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) sc[k] = reset_lane ? NINF : sc[k];
+                    for (int k = 0; k < 16; ++k) {
+                        if constexpr (LITE) KA_P(P, k) = reset_lane ? NINF : KA_P(P, k);
+                        else sc[k] = reset_lane ? NINF : sc[k];
+                    }
                     pres2 = reset_lane ? 0u : pres2;
                     pend_reset = false;
                 }
@@ -609,6 +671,7 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                     if (rem >= T) { rem -= T; ++q; }
                     if (t + 1 != T) {   // no frame T: keep the last band and labels
                         moved = true;
+                        mask_frames = 2;
                         const int32_t dlo = (int32_t)q - (int32_t)halfB;  // signed on purpose: s_max_i32, not a VALU usubsat
                         const uint32_t nlo = (uint32_t)(dlo > 0 ? dlo : 0);
                         if ((nlo >> 4) != blo) {
@@ -637,7 +700,28 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                 if constexpr (LITE) absum += __builtin_fabsf(rn);
                 // C. frame t
                 uint32_t word = 0;
-                frame_cells<M, ZL, 15, LITE>(sc, h1, h2, h3, e, vz, e0[dd & 1], mk, NINF, word, la, rn);
+                if constexpr (LITE) {
+                    const float e0t = e0[dd & 1];
+                    frame_scores<M, ZL, 3>(P, h1, h2, h3, E, vz, f32x2{e0t, e0t}, la, rn);
+                    // The band mask costs one v_cndmask per cell, a fifth of the frame's vector instructions.  It is
+                    // only NEEDED in the frame before a band step (the cells that become live must hold -inf), in
+                    // the first frame of a new band (cells that left it must die) and wherever the scores are looked
+                    // at (checkpoints = frame 4k+3; the last frame: masked after the loop).  In between, cells above
+                    // hi pick up "leaked" scores from the live cells below them, M-1 cells further per frame; moves
+                    // only go up, so a leak cannot reach a live cell except around the ring, through the >= 15 dead
+                    // slots between hi and lo.  With every fourth frame masked: at most 3 frames x 3 cells + the 3
+                    // cells lo reads.  mask_frames = 2 is set by step A when the band of frame t+1 differs.
+                    if (dd == D - 1) {
+                        mask_scores<15>(P, mk, NINF);
+                        mask_frames = (mask_frames > 1u ? mask_frames : 1u) - 1u;
+                    } else if (__builtin_expect(mask_frames != 0, 0)) {
+                        asm volatile("" ::: "memory");   // a real branch
+                        mask_scores<15>(P, mk, NINF);
+                        --mask_frames;
+                    }
+                } else {
+                    frame_cells<M, ZL, 15, LITE>(sc, h1, h2, h3, e, vz, e0[dd & 1], mk, NINF, word, la, rn);
+                }
                 gw[dd] = word;
                 // live <=> in band and (moved in from a live state, or stayed on a live state)
                 if constexpr (!LITE) pres2 = live_pairs(pres2, word, band2);
@@ -677,8 +761,10 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
             const char *ck = reinterpret_cast<const char *>(bp) + ((size_t)((tb + D) / kCkFrames) - 1) * 4096;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 v = {sc[4 * g], sc[4 * g + 1], sc[4 * g + 2], sc[4 * g + 3]};
-                asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" : : "v"((uint32_t)lane * 64u), "v"(v), "s"(ck), "i"(16 * g) : "memory");
+                const f32x4 v = {KA_P(P, 4 * g), KA_P(P, 4 * g + 1), KA_P(P, 4 * g + 2), KA_P(P, 4 * g + 3)};
+                // s_nop: the compiler stages all four groups through the same four registers and does not know
+                // that a store wider than 64 bits still reads them one cycle after it has issued
+                asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 0" : : "v"((uint32_t)lane * 64u), "v"(v), "s"(ck), "i"(16 * g) : "memory");
             }
         }
     }
@@ -690,6 +776,7 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
     for (int i = 0; i < D; ++i) row_wait<0>(rows[i]);
 
     int32_t *m = meta_of(meta, d.idx);
+    if constexpr (LITE) mask_scores<15>(P, mk, NINF);   // the last frame may have run unmasked
     if constexpr (LITE) {
         // Every partial path score is bounded by the sum of all |lp|: if each column's sum stays below
         // 1e30 nothing can have overflowed and every live state has a finite score, so live <=> score > -inf.
@@ -701,7 +788,10 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
         }
         pres2 = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) pres2 |= sc[k] != NINF ? (1u << (2 * k)) : 0u;
+        for (int k = 0; k < 16; ++k) {
+            sc[k] = KA_P(P, k);
+            pres2 |= sc[k] != NINF ? (1u << (2 * k)) : 0u;
+        }
     }
     // terminal state: the HIGHEST live position of frame T-1 (align.py:99-101)
     int best = -1;
