@@ -450,24 +450,7 @@ __device__ __forceinline__ uint32_t live_pairs(uint32_t live2, uint32_t word, ui
 // so the emission is added ONCE, after the max over the predecessors: 3-4 instructions per cell instead of
 // 5-7.  (The reference's arg-max ties are decided on the sums, align.py:83 - that needs the per-candidate sums
 // and is what backtrace_rc_kernel recomputes for the cells around the path.)
-template <int M>
-__device__ __forceinline__ float cell_blank_score(float a0, float a1, float a3, float e)
-{
-    if constexpr (M == 1) return a0 + e;
-    if constexpr (M <= 3) return __builtin_fmaxf(a0, a1) + e;
-    return __builtin_fmaxf(__builtin_fmaxf(a0, a1), a3) + e;
-}
-template <int M, bool ZL>
-__device__ __forceinline__ float cell_label_score(float a0, float a1, float a2, float a3, float e, float veto)
-{
-    if constexpr (M == 1) return a0 + e;
-    if constexpr (M == 2) return __builtin_fmaxf(a0, a1) + e;
-    if constexpr (ZL) a2 = __builtin_fminf(a2, veto);   // veto = -inf where the label value is 0 (move 2 not allowed), else +inf
-    if constexpr (M == 3) return __builtin_fmaxf(__builtin_fmaxf(a0, a1), a2) + e;
-    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), a2), a3) + e;
-}
-
-// The same without the emission (added two cells at a time by frame_scores)
+// These are the maxima; frame_scores adds the emissions, two cells at a time.
 template <int M>
 __device__ __forceinline__ float cell_blank_max(float a0, float a1, float a3)
 {
@@ -489,9 +472,17 @@ __device__ __forceinline__ float cell_label_max(float a0, float a1, float a2, fl
 // is then added to two cells per instruction (v_pk_add_f32: the vector ALU is what bounds this kernel).
 #define KA_P(P, k) (P)[2 * ((k) >> 2) + ((k) & 1)][((k) >> 1) & 1]
 // cells 4G+3..4G of one frame, in place (descending G: cell k reads the old k-1..k-3), NO band mask
+// emission gather: the next frame's log-prob row sits in LDS (one ds_write_b32 per frame), a label cell reads its
+// column with ds_read_b32.  ds_bpermute_b32 on the row register does the same without the write, but costs 7.0
+// cycles of the CU's LDS pipe per wave-instruction against 3.8 for the read (tools/ubench/lds_rates.hip) - with
+// 8 gathers per frame and 32 waves per CU that pipe was 75 % busy with them.
+__device__ __forceinline__ float lds_col(const float *row, int byte_addr)
+{
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(row) + byte_addr);
+}
 template <int M, bool ZL, int G>
 __device__ __forceinline__ void frame_scores(f32x2 (&P)[8], float h1, float h2, float h3, f32x2 (&E)[4], const float (&vz)[8],
-                                             f32x2 e00, const int (&la)[8], float next_row)
+                                             f32x2 e00, const int (&la)[8], const float *next_row)
 {
     const float b0 = P[2 * G][0], l0 = P[2 * G + 1][0], b1 = P[2 * G][1], l1 = P[2 * G + 1][1];
     const float p1 = G > 0 ? P[2 * (G > 0 ? G - 1 : 0) + 1][1] : h1;   // cell 4G-1 (label)
@@ -504,8 +495,8 @@ __device__ __forceinline__ void frame_scores(f32x2 (&P)[8], float h1, float h2, 
     mb[0] = cell_blank_max<M>(b0, p1, p3);
     P[2 * G + 1] = ml + E[G];
     P[2 * G] = mb + e00;
-    E[G][0] = bperm(la[2 * G], next_row);
-    E[G][1] = bperm(la[2 * G + 1], next_row);
+    E[G][0] = lds_col(next_row, la[2 * G]);
+    E[G][1] = lds_col(next_row, la[2 * G + 1]);
     __builtin_amdgcn_sched_barrier(0);   // as in frame_cells: keep the groups in program order
     if constexpr (G > 0) frame_scores<M, ZL, G - 1>(P, h1, h2, h3, E, vz, e00, la, next_row);
 }
@@ -522,7 +513,7 @@ __device__ __forceinline__ void mask_scores(f32x2 (&P)[8], BandMasks &mk, float 
 // The emission register of a label cell is refilled for the NEXT frame (ds_bpermute of the next
 // row) right after the cell has consumed it: one set of 8 emission registers, and a whole frame of
 // other work between a gather and its use.
-template <int M, bool ZL, int K, bool LITE>
+template <int M, bool ZL, int K>
 __device__ __forceinline__ void frame_cells(float (&sc)[16], float h1, float h2, float h3, float (&ec)[8],
                                             const float (&vz)[8], float e0, BandMasks &mk, float NINF, uint32_t &word,
                                             const int (&la)[8], float next_row)
@@ -533,28 +524,23 @@ __device__ __forceinline__ void frame_cells(float (&sc)[16], float h1, float h2,
     const float a3 = K >= 3 ? sc[K >= 3 ? K - 3 : 0] : (K == 2 ? h1 : (K == 1 ? h2 : h3));
     float m;
     if constexpr (K & 1) {
-        if constexpr (LITE) m = cell_label_score<M, ZL>(a0, a1, a2, a3, ec[K >> 1], vz[K >> 1]);
-        else cell_label<M, ZL>(a0, a1, a2, a3, ec[K >> 1], vz[K >> 1], m, word);
+        cell_label<M, ZL>(a0, a1, a2, a3, ec[K >> 1], vz[K >> 1], m, word);
         ec[K >> 1] = bperm(la[K >> 1], next_row);
     } else {
-        if constexpr (LITE) m = cell_blank_score<M>(a0, a1, a3, e0);
-        else cell_blank<M>(a0, a1, a3, e0, m, word);
+        cell_blank<M>(a0, a1, a3, e0, m, word);
     }
     sc[K] = select_by_mask(NINF, m, mk.at<K>());
     // keep the cells in program order, four at a time: left alone, the scheduler hoists the next frame's
     // gathers and interleaves all 16 cells, which costs ~16 VGPRs and ~60 spilled SGPRs
     if constexpr (K % 4 == 0) __builtin_amdgcn_sched_barrier(0);
-    if constexpr (K > 0) frame_cells<M, ZL, K - 1, LITE>(sc, h1, h2, h3, ec, vz, e0, mk, NINF, word, la, next_row);
+    if constexpr (K > 0) frame_cells<M, ZL, K - 1>(sc, h1, h2, h3, ec, vz, e0, mk, NINF, word, la, next_row);
 }
 
 // ---------------------------------------------------------------------------------------
 // forward DP, one wavefront per lattice
 // ---------------------------------------------------------------------------------------
-// LITE = checkpointed path: scores only (no compares, no back-pointer packing, no liveness word);
-// the score ring is stored every kCkFrames frames and backtrace_rc_kernel recomputes the back-pointers
-// of the ~100 cells around the path.  Valid when every log-prob is finite (then live <=> score > -inf);
-// the kernel checks that and flags the lattice for the exact kernels otherwise.
-template <int M, bool ZL, bool LITE>
+// Exact form: every cell's back-pointer is stored (the checkpointed form is forward_ck below).
+template <int M, bool ZL>
 __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
 {
     constexpr int D = kRowDepth;
@@ -568,16 +554,11 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
     const uint32_t dq = L / T, dr = L % T;
     const float NINF = ninf();
 
-    float sc[16];                           // exact kernel: one register per cell
-    f32x2 P[8];                             // checkpointed kernel: the same cells in pairs (see KA_P)
+    float sc[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) sc[k] = NINF;
     if (lane == 0) sc[0] = 0.0f;            // virtual state before frame 0 (align.py:57-58)
-#pragma unroll
-    for (int k = 0; k < 16; ++k) KA_P(P, k) = sc[k];
-    uint32_t mask_frames = 0;               // wave-uniform: frames (this one included) that must apply the band mask
     uint32_t pres2 = lane == 0 ? 1u : 0u;   // bit 2k: cell k holds a live state
-    float absum = 0.0f;                     // LITE: sum over frames of |lp[t, lane]| (finiteness check)
     bool pend_reset = false;                // wave-uniform: some lane was re-labelled for this frame
     bool reset_lane = false;                // per lane: this lane was re-labelled
 
@@ -613,13 +594,9 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
     // emissions of the label cells: e[i] holds frame t's value until cell 2i+1 has used it, then
     // frame t+1's (see frame_cells); the blank emission is a scalar, double-buffered by frame parity
     float e[8], e0[2];
-    f32x2 E[4];
 #pragma unroll
     for (int i = 0; i < 8; ++i) e[i] = bperm(la[i], rows[0]);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) E[i >> 1][i & 1] = e[i];
     e0[0] = first_lane(rows[0]);
-    if constexpr (LITE) absum = __builtin_fabsf(rows[0]);
 
     const uint32_t *bp = reinterpret_cast<const uint32_t *>(d.bp);   // wave-uniform row base
     const uint32_t lane_store_off = (uint32_t)lane * 16u;   // back-pointers: [t/4][block][t%4] dwords
@@ -640,8 +617,7 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                 // Halos of frame t, then the reset of lanes re-labelled in frame t-1 (they still held the scores of
                 // their OLD block, which their right neighbour has just read as its halo).  Done before step A so that
                 // A can write the flags of the NEXT frame in place (no per-frame copies of flags and band limits).
-                float h1 = wave_ror1(LITE ? KA_P(P, 15) : sc[15]), h2 = wave_ror1(LITE ? KA_P(P, 14) : sc[14]),
-                      h3 = wave_ror1(LITE ? KA_P(P, 13) : sc[13]);
+                float h1 = wave_ror1(sc[15]), h2 = wave_ror1(sc[14]), h3 = wave_ror1(sc[13]);
                 if (__builtin_expect(pend_reset, 0)) {
                     asm volatile("" ::: "memory");  // keep this rare block a real branch (no if-conversion)
                     // a lane re-labelled for this frame holds scores of its OLD block: its new
@@ -653,10 +629,7 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                     h2 = kill ? NINF : h2;
                     h3 = kill ? NINF : h3;
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        if constexpr (LITE) KA_P(P, k) = reset_lane ? NINF : KA_P(P, k);
-                        else sc[k] = reset_lane ? NINF : sc[k];
-                    }
+                    for (int k = 0; k < 16; ++k) sc[k] = reset_lane ? NINF : sc[k];
                     pres2 = reset_lane ? 0u : pres2;
                     pend_reset = false;
                 }
@@ -671,7 +644,6 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                     if (rem >= T) { rem -= T; ++q; }
                     if (t + 1 != T) {   // no frame T: keep the last band and labels
                         moved = true;
-                        mask_frames = 2;
                         const int32_t dlo = (int32_t)q - (int32_t)halfB;  // signed on purpose: s_max_i32, not a VALU usubsat
                         const uint32_t nlo = (uint32_t)(dlo > 0 ? dlo : 0);
                         if ((nlo >> 4) != blo) {
@@ -694,37 +666,15 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                 // B. row t+1 (its emissions are gathered while frame t is computed).  It was issued D-1
                 // frames ago; since then (D-2) frames each issued one row load, and the group store that
                 // follows frame 4k+3 lies in between unless dd = 3 (rare label reloads only add younger ops)
-                if (!LITE && dd < D - 1) row_wait<D - 1>(rows[(dd + 1) % D]); else row_wait<D - 2>(rows[(dd + 1) % D]);
+                if (dd < D - 1) row_wait<D - 1>(rows[(dd + 1) % D]); else row_wait<D - 2>(rows[(dd + 1) % D]);
                 const float rn = rows[(dd + 1) % D];
                 e0[(dd + 1) & 1] = first_lane(rn);
-                if constexpr (LITE) absum += __builtin_fabsf(rn);
                 // C. frame t
                 uint32_t word = 0;
-                if constexpr (LITE) {
-                    const float e0t = e0[dd & 1];
-                    frame_scores<M, ZL, 3>(P, h1, h2, h3, E, vz, f32x2{e0t, e0t}, la, rn);
-                    // The band mask costs one v_cndmask per cell, a fifth of the frame's vector instructions.  It is
-                    // only NEEDED in the frame before a band step (the cells that become live must hold -inf), in
-                    // the first frame of a new band (cells that left it must die) and wherever the scores are looked
-                    // at (checkpoints = frame 4k+3; the last frame: masked after the loop).  In between, cells above
-                    // hi pick up "leaked" scores from the live cells below them, M-1 cells further per frame; moves
-                    // only go up, so a leak cannot reach a live cell except around the ring, through the >= 15 dead
-                    // slots between hi and lo.  With every fourth frame masked: at most 3 frames x 3 cells + the 3
-                    // cells lo reads.  mask_frames = 2 is set by step A when the band of frame t+1 differs.
-                    if (dd == D - 1) {
-                        mask_scores<15>(P, mk, NINF);
-                        mask_frames = (mask_frames > 1u ? mask_frames : 1u) - 1u;
-                    } else if (__builtin_expect(mask_frames != 0, 0)) {
-                        asm volatile("" ::: "memory");   // a real branch
-                        mask_scores<15>(P, mk, NINF);
-                        --mask_frames;
-                    }
-                } else {
-                    frame_cells<M, ZL, 15, LITE>(sc, h1, h2, h3, e, vz, e0[dd & 1], mk, NINF, word, la, rn);
-                }
+                frame_cells<M, ZL, 15>(sc, h1, h2, h3, e, vz, e0[dd & 1], mk, NINF, word, la, rn);
                 gw[dd] = word;
                 // live <=> in band and (moved in from a live state, or stayed on a live state)
-                if constexpr (!LITE) pres2 = live_pairs(pres2, word, band2);
+                pres2 = live_pairs(pres2, word, band2);
                 // prefetch the row of frame t+D (the last row again once there is none: never consumed)
                 row_reload(rows[dd], lane_off, row_ahead);
                 row_ahead += t + D + 1 < T ? ld : 0;
@@ -751,22 +701,10 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                 }
             }
         }
-        if constexpr (!LITE) {
-            // one 16-byte store per lane per 4 frames.  saddr (uniform pointer to the group) + voffset
-            // (lane*16): no per-lane 64-bit address registers
-            const u32x4 words = {gw[0], gw[1], gw[2], gw[3]};
-            asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(lane_store_off), "v"(words), "s"(bp + (size_t)tb * 64) : "memory");
-        } else if (((tb + D) & (kCkFrames - 1)) == 0 && tb + D < T) {
-            // checkpoint (tb+D)/kCkFrames: the scores after frame tb+D-1, [lane][16 cells], 4 KB
-            const char *ck = reinterpret_cast<const char *>(bp) + ((size_t)((tb + D) / kCkFrames) - 1) * 4096;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 v = {KA_P(P, 4 * g), KA_P(P, 4 * g + 1), KA_P(P, 4 * g + 2), KA_P(P, 4 * g + 3)};
-                // s_nop: the compiler stages all four groups through the same four registers and does not know
-                // that a store wider than 64 bits still reads them one cycle after it has issued
-                asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 0" : : "v"((uint32_t)lane * 64u), "v"(v), "s"(ck), "i"(16 * g) : "memory");
-            }
-        }
+        // one 16-byte store per lane per 4 frames.  saddr (uniform pointer to the group) + voffset
+        // (lane*16): no per-lane 64-bit address registers
+        const u32x4 words = {gw[0], gw[1], gw[2], gw[3]};
+        asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(lane_store_off), "v"(words), "s"(bp + (size_t)tb * 64) : "memory");
     }
 
     // Drain the row prefetches that are still in flight (the last D frames prefetch clamped rows that are
@@ -776,22 +714,221 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
     for (int i = 0; i < D; ++i) row_wait<0>(rows[i]);
 
     int32_t *m = meta_of(meta, d.idx);
-    if constexpr (LITE) mask_scores<15>(P, mk, NINF);   // the last frame may have run unmasked
-    if constexpr (LITE) {
-        // Every partial path score is bounded by the sum of all |lp|: if each column's sum stays below
-        // 1e30 nothing can have overflowed and every live state has a finite score, so live <=> score > -inf.
-        // Otherwise (an infinity, a NaN, absurd magnitudes) hand the lattice to the exact kernels.
-        const bool ok = absum < 1e30f;
-        if (__builtin_amdgcn_ballot_w64(!ok)) {
-            if (lane == 0) atomicOr(&m[2], kFlagExact);
-            return;
-        }
-        pres2 = 0;
+    // terminal state: the HIGHEST live position of frame T-1 (align.py:99-101)
+    int best = -1;
+    if (pres2) best = blk * 16 + ((31 - __clz((int)pres2)) >> 1);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            sc[k] = KA_P(P, k);
-            pres2 |= sc[k] != NINF ? (1u << (2 * k)) : 0u;
+    for (int off = 32; off >= 1; off >>= 1) {
+        const int o = __shfl_xor(best, off);
+        best = o > best ? o : best;
+    }
+    if (best < 0) {
+        if (lane == 0) {
+            m[1] = -1;
+            atomicMin(&m[0], kStatusEmptyBeam);
         }
+    } else if ((best >> 4) == blk) {
+        float v = sc[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v = (best & 15) == k ? sc[k] : v;
+        m[1] = best;
+        m[3] = __builtin_bit_cast(int32_t, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// forward DP of the checkpointed form: scores only, one wavefront per lattice
+//
+// Same ring, labels, band and row pipeline as forward_w16, but the loop is arranged so that the frame that
+// does not step the band - most frames - executes nothing but its own arithmetic and ONE scalar compare
+// and branch:
+//   * the halos of frame t+1 are taken at the end of frame t and carried in registers, so the re-labelling
+//     of lanes, their reset and the band masks all live in one rare block after the cells;
+//   * the band mask (a v_cndmask per cell) is applied only where it is needed: in the frame before a band
+//     step (the cells that become live must hold -inf), in the first frame of a new band (cells that left
+//     it must die) - both inside the rare block, the second by forcing the next frame through it - and in
+//     every fourth frame (checkpoints are taken there).  In between, cells above hi pick up "leaked" scores
+//     from the live cells below them, M-1 cells further per frame; moves only go up, so a leak cannot reach
+//     a live cell except around the ring, through the >= 15 dead slots between hi and lo: at most 3 frames
+//     x 3 cells + the 3 cells lo reads.
+// ---------------------------------------------------------------------------------------
+template <int M, bool ZL>
+__device__ __forceinline__ void forward_ck(const Lattice &d, int32_t *meta)
+{
+    constexpr int D = kRowDepth;
+    const int lane = threadIdx.x;
+    const uint32_t T = (uint32_t)__builtin_amdgcn_readfirstlane(d.T);
+    const uint32_t L = (uint32_t)__builtin_amdgcn_readfirstlane(d.L);
+    const uint32_t B = (uint32_t)__builtin_amdgcn_readfirstlane(d.beam);
+    const uint32_t halfB = B >> 1;
+    const uint32_t dq = L / T, dr = L % T;
+    const float NINF = ninf();
+
+    f32x2 P[8];                             // cell k of the lane: KA_P(P, k)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) KA_P(P, k) = NINF;
+    if (lane == 0) KA_P(P, 0) = 0.0f;       // virtual state before frame 0 (align.py:57-58)
+    float absum = 0.0f;                     // sum over frames of |lp[t, lane]| (finiteness check)
+
+    int blk = lane;                         // block of 16 positions this lane currently owns
+    uint32_t blo = 0;                       // lo >> 4
+    int la[8];
+    float vz[8];
+    gci32_t labx = (gci32_t)d.labx;
+    load_block_labels(labx, blk, la);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vz[i] = (ZL && la[i] == 0) ? NINF : __builtin_inff();
+
+    uint32_t q = 0, rem = 0;                // floor(L*t/T) and its remainder, advanced per frame
+    uint32_t lo = 0, hi = B < L ? B : L;    // band of frame 0
+    BandMasks mk;
+    band_rebuild(mk, lo, hi);
+
+    const uint32_t lane_off = (lane < d.V ? (uint32_t)lane : 0u) * 4u;
+    const char *lp = reinterpret_cast<const char *>(d.lp);
+    const size_t ld = (size_t)d.ld * 4;  // row pitch in bytes
+    float rows[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const uint32_t tt = (uint32_t)i < T ? (uint32_t)i : T - 1;
+        rows[i] = row_load(lane_off, lp + (size_t)tt * ld);
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) row_wait<0>(rows[i]);
+    f32x2 E[4];                             // emissions of the label cells (see frame_scores)
+    float e0[2];                            // blank emission, double-buffered by frame parity
+    __shared__ float lrow[64];              // row t+1 while frame t is computed (the workgroup is this one wavefront)
+    lrow[lane] = rows[0];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) E[i >> 1][i & 1] = lds_col(lrow, la[i]);
+    e0[0] = first_lane(rows[0]);
+    absum = __builtin_fabsf(rows[0]);
+
+    const char *ckp = reinterpret_cast<const char *>(d.bp);
+    const char *row_ahead = lp + (size_t)(D < T ? D : T - 1) * ld;   // row min(t+D, T-1) of the current frame t
+    const uint32_t thr_real = dq != 0 ? 0u : T;   // floor(L*t/T) moves in this frame <=> rem + dr >= thr_real
+    uint32_t thr = thr_real;                // 0 for one frame after a band step: that frame must come through the rare block
+    asm("" : "+s"(thr));                    // (opaque: one s_cmp + s_cbranch per frame instead of a boolean expression)
+    // halos of frame 0: lane 63's cells 13..15 of the initial state
+    float h1 = wave_ror1(KA_P(P, 15)), h2 = wave_ror1(KA_P(P, 14)), h3 = wave_ror1(KA_P(P, 13));
+    for (uint32_t tb = 0; tb < T; tb += D) {
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) {
+            const uint32_t t = tb + dd;
+            if (t < T) {
+                // row t+1 (its emissions are gathered while frame t is computed): issued D-1 frames ago, D-2
+                // younger row loads behind it (checkpoint stores and label reloads only add younger operations)
+                row_wait<D - 2>(rows[(dd + 1) % D]);
+                const float rn = rows[(dd + 1) % D];
+                lrow[lane] = rn;                 // (LDS operations of a wave execute in order: the reads of row t are done)
+                e0[(dd + 1) & 1] = first_lane(rn);
+                absum += __builtin_fabsf(rn);
+                const float e0t = e0[dd & 1];
+                frame_scores<M, ZL, 3>(P, h1, h2, h3, E, vz, f32x2{e0t, e0t}, la, lrow);
+                // prefetch the row of frame t+D (the last row again once there is none: never consumed)
+                row_reload(rows[dd], lane_off, row_ahead);
+                row_ahead += t + D + 1 < T ? ld : 0;
+                if (dd == D - 1) {
+                    mask_scores<15>(P, mk, NINF);
+                    if (((tb + D) & (kCkFrames - 1)) == 0 && tb + D < T) {
+                        // checkpoint (tb+D)/kCkFrames: the scores after frame tb+D-1, [lane][16 cells], 4 KB.  Taken
+                        // before the rare block resets re-labelled lanes: their old positions are still inputs
+                        // of frame tb+D.
+                        const char *ck = ckp + ((size_t)((tb + D) / kCkFrames) - 1) * 4096;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 v = {KA_P(P, 4 * g), KA_P(P, 4 * g + 1), KA_P(P, 4 * g + 2), KA_P(P, 4 * g + 3)};
+                            // s_nop: the compiler stages all four groups through the same four registers and does not
+                            // know that a store wider than 64 bits still reads them one cycle after it has issued
+                            asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 0" : : "v"((uint32_t)lane * 64u), "v"(v), "s"(ck), "i"(16 * g) : "memory");
+                        }
+                    }
+                }
+                h1 = wave_ror1(KA_P(P, 15));
+                h2 = wave_ror1(KA_P(P, 14));
+                h3 = wave_ror1(KA_P(P, 13));
+                rem += dr;
+                if (__builtin_expect(rem >= thr, 0)) {
+                    asm volatile("" ::: "memory");  // a real branch: the common frame pays an add, a compare and a jump
+                    thr = thr_real;
+                    if (dd != D - 1) {
+                        mask_scores<15>(P, mk, NINF);
+                        h1 = wave_ror1(KA_P(P, 15));
+                        h2 = wave_ror1(KA_P(P, 14));
+                        h3 = wave_ror1(KA_P(P, 13));
+                    }
+                    if (rem >= thr_real) {
+                        q += dq;
+                        if (rem >= T) { rem -= T; ++q; }
+                        if (t + 1 != T) {   // no frame T: keep the last band and labels
+                            const int32_t dlo = (int32_t)q - (int32_t)halfB;  // signed on purpose: s_max_i32, not a VALU usubsat
+                            const uint32_t nlo = (uint32_t)(dlo > 0 ? dlo : 0);
+                            const uint32_t nhi = (L - nlo < B) ? L : nlo + B;
+                            if ((nlo >> 4) != blo) {
+                                // re-label the lanes whose block lo has passed.  They held scores of their OLD block,
+                                // which their right neighbour has just taken as its halo; their new positions were not
+                                // live in frame t.  A lane's left halo is valid unless its left neighbour was
+                                // re-labelled in the same step (then nobody held those positions).
+                                blo = nlo >> 4;
+                                const int nb = (int)blo + ((lane - (int)blo) & 63);
+                                const bool reset_lane = nb != blk;
+                                if (reset_lane) {
+                                    blk = nb;
+                                    load_block_labels(labx, blk, la);
+#pragma unroll
+                                    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(la[i]));
+                                }
+                                const bool left_reset = __builtin_amdgcn_update_dpp(0, (int)reset_lane, 0x13C, 0xF, 0xF, false) != 0;
+                                const bool kill = reset_lane && left_reset;
+                                h1 = kill ? NINF : h1;
+                                h2 = kill ? NINF : h2;
+                                h3 = kill ? NINF : h3;
+#pragma unroll
+                                for (int k = 0; k < 16; ++k) KA_P(P, k) = reset_lane ? NINF : KA_P(P, k);
+                                // emissions of frame t+1 with the new labels (the cells gathered them with the old ones)
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) E[i >> 1][i & 1] = lds_col(lrow, la[i]);
+                                if constexpr (ZL) {
+#pragma unroll
+                                    for (int i = 0; i < 8; ++i) vz[i] = la[i] == 0 ? NINF : __builtin_inff();
+                                }
+                            }
+                            if (nlo != lo || nhi != hi) {
+                                if (nhi - hi <= 1u && nlo - lo <= 1u) {
+                                    if (nhi != hi) band_toggle(mk, hi);
+                                    if (nlo != lo) band_toggle(mk, lo);
+                                } else {
+                                    band_rebuild(mk, nlo, nhi);
+                                }
+                                lo = nlo;
+                                hi = nhi;
+                                thr = 0;   // frame t+1 is the first of a new band: it must be masked
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) row_wait<0>(rows[i]);   // drain the prefetches (see forward_w16)
+
+    int32_t *m = meta_of(meta, d.idx);
+    mask_scores<15>(P, mk, NINF);   // the last frame may have run unmasked
+    // Every partial path score is bounded by the sum of all |lp|: if each column's sum stays below 1e30 nothing
+    // can have overflowed and every live state has a finite score, so live <=> score > -inf.  Otherwise (an
+    // infinity, a NaN, absurd magnitudes) hand the lattice to the exact kernels.
+    const bool ok = absum < 1e30f;
+    if (__builtin_amdgcn_ballot_w64(!ok)) {
+        if (lane == 0) atomicOr(&m[2], kFlagExact);
+        return;
+    }
+    float sc[16];
+    uint32_t pres2 = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        sc[k] = KA_P(P, k);
+        pres2 |= sc[k] != NINF ? (1u << (2 * k)) : 0u;
     }
     // terminal state: the HIGHEST live position of frame T-1 (align.py:99-101)
     int best = -1;
@@ -829,7 +966,7 @@ __global__ __launch_bounds__(64, KA_FWD_MIN_WAVES) void forward_w16_kernel(const
     const int flags = __builtin_amdgcn_readfirstlane(meta_of(meta, d.idx)[2]);
     if (((flags & kFlagZeroLabel) != 0) != ZL) return;
     if (only_flagged && !(flags & kFlagExact)) return;
-    forward_w16<M, ZL, false>(d, meta);
+    forward_w16<M, ZL>(d, meta);
 }
 template <int M, bool ZL>
 __global__ __launch_bounds__(64, KA_FWD_MIN_WAVES) void forward_ck_kernel(const Lattice *__restrict__ lats, int32_t *meta)
@@ -837,7 +974,7 @@ __global__ __launch_bounds__(64, KA_FWD_MIN_WAVES) void forward_ck_kernel(const 
     const Lattice &d = lats[blockIdx.x];
     const int flags = __builtin_amdgcn_readfirstlane(meta_of(meta, d.idx)[2]);
     if (((flags & kFlagZeroLabel) != 0) != ZL) return;
-    forward_w16<M, ZL, true>(d, meta);
+    forward_ck<M, ZL>(d, meta);
 }
 
 // ---------------------------------------------------------------------------------------
