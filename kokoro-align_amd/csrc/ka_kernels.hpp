@@ -747,10 +747,10 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
 //   * the band mask (a v_cndmask per cell) is applied only where it is needed: in the frame before a band
 //     step (the cells that become live must hold -inf), in the first frame of a new band (cells that left
 //     it must die) - both inside the rare block, the second by forcing the next frame through it - and in
-//     every fourth frame (checkpoints are taken there).  In between, cells above hi pick up "leaked" scores
-//     from the live cells below them, M-1 cells further per frame; moves only go up, so a leak cannot reach
-//     a live cell except around the ring, through the >= 15 dead slots between hi and lo: at most 3 frames
-//     x 3 cells + the 3 cells lo reads.
+//     every eighth (narrow gap: fourth) frame; checkpoints are taken there.  In between, cells above hi pick
+//     up "leaked" scores from the live cells below them, M-1 cells further per frame; moves only go up, so a
+//     leak cannot reach a live cell except around the ring, through the >= 15 dead slots between hi and lo:
+//     at most 3 frames x 3 cells + the 3 cells lo reads (7 frames when there are >= 24 dead slots).
 // ---------------------------------------------------------------------------------------
 template <int M, bool ZL>
 __device__ __forceinline__ void forward_ck(const Lattice &d, int32_t *meta)
@@ -807,6 +807,9 @@ __device__ __forceinline__ void forward_ck(const Lattice &d, int32_t *meta)
     const char *ckp = reinterpret_cast<const char *>(d.bp);
     const char *row_ahead = lp + (size_t)(D < T ? D : T - 1) * ld;   // row min(t+D, T-1) of the current frame t
     const uint32_t thr_real = dq != 0 ? 0u : T;   // floor(L*t/T) moves in this frame <=> rem + dr >= thr_real
+    // static mask: frame 8k+7 when the ring has at least 8*(M-1) dead slots (7 unmasked frames leak 7*(M-1) cells and
+    // lo reads M-1 below itself), else frame 4k+3.  Checkpoints (frame 32k+31) are masked frames either way.
+    const uint32_t mask_every4 = 1024u - (B < L ? B : L) >= 8u * (M - 1) ? 0u : 4u;
     uint32_t thr = thr_real;                // 0 for one frame after a band step: that frame must come through the rare block
     asm("" : "+s"(thr));                    // (opaque: one s_cmp + s_cbranch per frame instead of a boolean expression)
     // halos of frame 0: lane 63's cells 13..15 of the initial state
@@ -828,7 +831,7 @@ __device__ __forceinline__ void forward_ck(const Lattice &d, int32_t *meta)
                 // prefetch the row of frame t+D (the last row again once there is none: never consumed)
                 row_reload(rows[dd], lane_off, row_ahead);
                 row_ahead += t + D + 1 < T ? ld : 0;
-                if (dd == D - 1) {
+                if (dd == D - 1 && ((tb | mask_every4) & 4u) != 0) {
                     mask_scores<15>(P, mk, NINF);
                     if (((tb + D) & (kCkFrames - 1)) == 0 && tb + D < T) {
                         // checkpoint (tb+D)/kCkFrames: the scores after frame tb+D-1, [lane][16 cells], 4 KB.  Taken
@@ -851,7 +854,7 @@ __device__ __forceinline__ void forward_ck(const Lattice &d, int32_t *meta)
                 if (__builtin_expect(rem >= thr, 0)) {
                     asm volatile("" ::: "memory");  // a real branch: the common frame pays an add, a compare and a jump
                     thr = thr_real;
-                    if (dd != D - 1) {
+                    if (dd != D - 1 || ((tb | mask_every4) & 4u) == 0) {
                         mask_scores<15>(P, mk, NINF);
                         h1 = wave_ror1(KA_P(P, 15));
                         h2 = wave_ror1(KA_P(P, 14));
