@@ -841,9 +841,11 @@ __device__ __forceinline__ void forward_ck(const Lattice &d, int32_t *meta)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const f32x4 v = {KA_P(P, 4 * g), KA_P(P, 4 * g + 1), KA_P(P, 4 * g + 2), KA_P(P, 4 * g + 3)};
-                            // s_nop: the compiler stages all four groups through the same four registers and does not
-                            // know that a store wider than 64 bits still reads them one cycle after it has issued
-                            asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 0" : : "v"((uint32_t)lane * 64u), "v"(v), "s"(ck), "i"(16 * g) : "memory");
+                            // s_nop 1: the compiler stages all four groups through the same four registers and does not
+                            // know that on gfx940+ a store wider than 64 bits still reads its data registers for two
+                            // wait states after it has issued (one was not enough: under load the first dword of a
+                            // group came out as the next group's - tools/check_batch.py, tests: batch vs oracle)
+                            asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" : : "v"((uint32_t)lane * 64u), "v"(v), "s"(ck), "i"(16 * g) : "memory");
                         }
                     }
                 }

@@ -287,6 +287,33 @@ def test_many_lattices_under_memory_pressure(ka):
         assert np.array_equal(batch.best_labels[i].cpu().numpy(), want[1]), i
 
 
+def test_full_occupancy_batch_sampled_against_the_oracle(ka):
+    """Regression: 4096 lattices (4 wavefronts per SIMD) and a random sample of them against the oracle, all three
+    outputs.  The checkpointed forward kernel once staged its 16-byte checkpoint stores through one set of
+    registers with a single wait state between a store and the next write of its data registers; gfx950 needs
+    two, and only under load did the first dword of a group come out as the next group's - every end position
+    was right, lattice 0 was right, and about half of the other paths differed from the reference for a few
+    thousand frames."""
+    import torch
+    B, T, V, S = 4096, 4000, 64, 400
+    lib = ka.load_library()
+    lps = torch.empty((B, T, V), dtype=torch.float32, device="cuda")
+    labs = torch.empty((B, S), dtype=torch.int32, device="cuda")
+    assert lib.ka_hash_logprobs_batch_f32(lps.data_ptr(), B, T, V, V, T * V, 9000, None) == 0
+    assert lib.ka_hash_labels_batch_i32(labs.data_ptr(), B, S, V, S, 9000, None) == 0
+    torch.cuda.synchronize()
+    from kokoro_align_amd.align import DeviceBatch
+    batch = DeviceBatch([lps[i] for i in range(B)], [labs[i] for i in range(B)])
+    batch.run()
+    batch.run()
+    sample = sorted(set([0, B - 1] + np.random.default_rng(4).integers(0, B, size=30).tolist()))
+    for i in sample:
+        want = O.ctc_best_path_c(O.hash_logprobs(T, V, 9000 + i), O.hash_labels(S, V, 9000 + i))
+        assert np.array_equal(batch.path[i].cpu().numpy(), want[0]), i
+        assert np.array_equal(batch.best_labels[i].cpu().numpy(), want[1]), i
+        assert np.array_equal(batch.best_scores[i].cpu().numpy().view(np.int32), want[2].view(np.int32)), i
+
+
 def test_cfg5_long_form_band(ka):
     """BASELINE configs[4] with the default band: T=500000 x V=64, S=50000 (L=100001); 128 MB of back-pointers."""
     import torch

@@ -14,6 +14,12 @@ reports every v_mov / DPP mov whose SOURCE is a register written by an inline-as
 have landed.  Program order is not execution order across branches, so this is a lint, not a proof: it is
 exact for the straight-line unrolled frame code and for the copies a compiler puts in front of a back-edge.
 
+A second check covers the other thing hipcc cannot see inside inline asm: a store of more than 64 bits keeps
+reading its data registers for two wait states after it has issued (gfx940+), so the next two instruction slots
+must not write them.  The compiler honours that for its own stores; behind an inline-asm store it happily
+refills a staging register in the very next instruction (first seen as checkpoints whose first dword came from
+the next group, only under load).
+
     python tools/lint_inflight.py [path/to/ka_engine.s]      exit status 1 when something is reported
 """
 import os
@@ -89,6 +95,26 @@ def check(path):
                 for r in regs(mo.group(2)):
                     if r in pending and not srcs:
                         pending.pop(r, None)
+        # wide inline-asm stores: nothing may write their data registers within two wait states
+        lines = [ln for ln in k.split("\n") if ln.strip() and not ln.lstrip().startswith((";", ".", "//")) and not ln.rstrip().endswith(":")]
+        for i, ln in enumerate(lines):
+            ms = re.match(r"\s*(global_store_dwordx[34]|buffer_store_dwordx[34]|flat_store_dwordx[34])\s+(.*)", ln)
+            if not ms:
+                continue
+            ops = [o.strip() for o in ms.group(2).split(",")]
+            data = regs(ops[1]) if len(ops) > 1 else []
+            waited, j = 0, i + 1
+            while waited < 2 and j < len(lines):
+                nx = lines[j]
+                mn = re.match(r"\s*s_nop\s+(\d+)", nx)
+                if mn:
+                    waited += int(mn.group(1)) + 1
+                else:
+                    mo = re.match(r"\s*(v_\w+|ds_\w+|global_load\w*|buffer_load\w*)\s+(v\[?[0-9:]+\]?)", nx)
+                    if mo and not nx.lstrip().startswith(("v_cmp", "v_cmpx", "ds_write", "ds_bpermute")) and set(regs(mo.group(2))) & set(data):
+                        found.append(f"{ln.strip()}  ->  {nx.strip()}")
+                    waited += 1
+                j += 1
         report.append((m.group(1), found))
         total += len(found)
     return report, total
@@ -100,6 +126,6 @@ if __name__ == "__main__":
     rep, total = check(path)
     for name, found in rep:
         if found:
-            print(f"{name}: {len(found)} copies of registers whose load may be in flight, e.g. {found[:3]}")
+            print(f"{name}: {len(found)} hazards (copy of a register whose load may be in flight / write of a wide store's data), e.g. {found[:3]}")
     print(f"{len(rep)} kernels checked, {total} suspicious copies")
     sys.exit(1 if total else 0)
