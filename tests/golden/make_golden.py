@@ -359,7 +359,74 @@ def make_g5():
     print("g5: written;", len(out["combine_files"]["1"]["metadata"].splitlines()), "metadata lines (remove_wordsep=True)")
 
 
+def make_g6():
+    """Silence splitting: the reference's own get_silent_ranges / get_split_points (kokoro_align/preprocess.py:38-97)
+    on synthetic waveforms (oracle.frontend_oracle.hash_waveform: only the recipe is stored, not the audio).
+    kokoro_align/preprocess.py imports torchaudio at module import; the two functions pinned here are plain NumPy
+    and never touch it, so - as for g4 - a placeholder module object is registered for the import only.  The MFCC
+    transform itself (torchaudio.transforms.MFCC) cannot be pinned: torchaudio is not in this image."""
+    ph = types.ModuleType("torchaudio")
+    sys.modules.setdefault("torchaudio", ph)
+    from kokoro_align import preprocess as rpre
+    from oracle.frontend_oracle import hash_waveform, split_parameters
+
+    sr = 22050
+    par = split_parameters(sr, 512)
+    rng = np.random.default_rng(6)
+
+    def speech(total_s, voiced=(0.4, 6.0), silent=(0.05, 1.2), lead=0.0, tail=0.0, amp=(0.05, 0.6), floor=0.0):
+        """pieces of one synthetic recording: voiced bursts separated by silences (seconds -> samples)"""
+        pieces, t = [], lead
+        if floor:
+            pieces.append((0, int(total_s * sr), floor))
+        while t < total_s - tail:
+            d = float(rng.uniform(*voiced))
+            pieces.append((int(t * sr), int(min(t + d, total_s - tail) * sr), float(rng.uniform(*amp))))
+            t += d + float(rng.uniform(*silent))
+        return int(total_s * sr), pieces
+
+    cases = []
+    recipes = [
+        ("typical", speech(70.0)),
+        ("leading and trailing silence", speech(45.0, lead=1.3, tail=2.1)),
+        ("noise floor", speech(60.0, floor=0.002)),
+        ("short pauses only: the minimum silence is halved until pieces are short enough", speech(50.0, voiced=(1.0, 4.0), silent=(0.06, 0.2))),
+        ("long pauses, short bursts: many merges", speech(40.0, voiced=(0.3, 1.0), silent=(0.3, 0.9))),
+        ("one burst", (int(6.0 * sr), [(int(1.0 * sr), int(4.0 * sr), 0.3)])),
+        ("two bursts, pause in the middle", (int(9.0 * sr), [(0, int(4.0 * sr), 0.3), (int(5.0 * sr), int(9.0 * sr), 0.2)])),
+        ("no silence at all and too long: cannot be split", (int(20.0 * sr), [(0, int(20.0 * sr), 0.3)])),
+        ("length not a multiple of the window", speech(33.3337)),
+        ("quiet recording", speech(55.0, amp=(0.001, 0.004))),
+        ("digital silence, too long: raises", (int(20.0 * sr), [])),
+        ("digital silence, short", (int(5.0 * sr), [])),
+    ]
+    for k, (name, (n, pieces)) in enumerate(recipes):
+        seed = 600 + k
+        x = hash_waveform(n, seed, pieces)
+        try:
+            pts = rpre.get_split_points(x, par["minimum_silent_frames"], par["minimum_split_distance"],
+                                        par["maximum_split_distance"], par["window_size"])
+            case = {"status": 0, "split_points": [int(v) for v in pts]}
+        except ValueError as e:
+            case = {"status": 1, "error": str(e)}
+        case.update(name=name, n=n, seed=seed, pieces=[[int(a), int(b), float(v)] for a, b, v in pieces])
+        cases.append(case)
+    # get_silent_ranges on hand-made masks
+    masks = ["0011100111000", "1110001110011", "1111", "0000", "10", "01", "010", "101", "1100110011", "0110"]
+    sil = []
+    for mk in masks:
+        v = np.array([c == "1" for c in mk])
+        try:
+            sil.append({"mask": mk, "ranges": rpre.get_silent_ranges(v).tolist()})
+        except Exception as e:   # noqa: BLE001  (recorded as the reference's behaviour)
+            sil.append({"mask": mk, "raises": type(e).__name__})
+    out = {"sample_rate": sr, "parameters": par, "cases": cases, "silent_ranges": sil}
+    with open(os.path.join(HERE, "g6_split.json"), "wt") as f:
+        json.dump(out, f)
+    print("g6: written;", [(c["name"][:20], c["status"], len(c.get("split_points", []))) for c in cases])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
     for w in which:
-        {"g1": make_g1, "g2": make_g2, "g3": make_g3, "g4": make_g4, "g5": make_g5}[w]()
+        {"g1": make_g1, "g2": make_g2, "g3": make_g3, "g4": make_g4, "g5": make_g5, "g6": make_g6}[w]()

@@ -63,3 +63,9 @@ def g4():
 def g5():
     with open(os.path.join(GOLDEN, "g5_pipeline.json")) as f:
         return json.load(f)
+
+
+def g6():
+    """Silence-splitting goldens (reference get_split_points / get_silent_ranges on synthetic recordings)."""
+    with open(os.path.join(GOLDEN, "g6_split.json")) as f:
+        return json.load(f)
