@@ -158,6 +158,29 @@ int ka_lstm_step_f32(const float *gin, int64_t ldg, const float *rec, int64_t re
 int ka_lstm_layer_f32(const float *gin, int64_t ldg, const float *w_hh, float *out, int64_t ldo, const int32_t *seq_off,
                       const int32_t *seq_len, int32_t nseq, int32_t H, void *stream);
 
+/*
+ * Audio front end (kokoro_align/preprocess.py:51-131).  Device pointers throughout.
+ *
+ * ka_window_energy_f32: out[w] = mean(x[256w : 256w+256]**2), the level get_split_points thresholds
+ *   (preprocess.py:53-54), float32 summed in NumPy's order for a contiguous row of 256 so that the split points
+ *   are the reference's bit for bit (the remaining steps of get_split_points run on the host on these values).
+ * ka_stft_frames_f32: windowed frames of torchaudio's Spectrogram as called by split_audio (preprocess.py:110-127:
+ *   center=True, reflect padding, frame f of a segment starts at f*hop - n_fft/2) for all segments of a recording:
+ *   frames[frame_off[s] + f][k] = window[k] * y[seg_start[s] + reflect(f*hop - n_fft/2 + k)], f < 1 + seg_len[s]/hop.
+ *   Every segment must be longer than n_fft/2 samples (as the reference's transform requires).
+ * ka_power_f32: power[r][c] = re^2 + im^2 of a transform stored [n][2*nf] = (real | imaginary) - the output of one
+ *   library GEMM of the frames with the [n_fft][2*nf] cosine / sine basis.
+ * ka_power_to_db_f32: AmplitudeToDB("power", top_db) per segment, in place: x = 10*log10(max(x, 1e-10)), then
+ *   x = max(x, max over the segment - top_db).  frame_off has nseg+1 entries; segmax [nseg] must hold -inf on entry
+ *   and returns the segment maxima.
+ */
+int ka_window_energy_f32(const float *x, int64_t n_windows, int32_t window, float *out, void *stream);
+int ka_stft_frames_f32(const float *y, const int64_t *seg_start, const int64_t *seg_len, const int64_t *frame_off, int32_t nseg,
+                       int64_t max_frames, int32_t n_fft, int32_t hop, const float *window, float *frames, int64_t ld, void *stream);
+int ka_power_f32(const float *reim, int64_t ld_in, float *power, int64_t ld_out, int64_t n, int32_t nf, void *stream);
+int ka_power_to_db_f32(float *x, int64_t ld, int32_t cols, const int64_t *frame_off, int32_t nseg, int64_t max_frames, float top_db,
+                       float *segmax, void *stream);
+
 /* Bit-reproducible synthetic inputs generated in HBM (same definition as the CPU oracle's
  * hash generator):  lp[t,c] = -8*u24(mix(seed, t*V+c)),
  * labels[k] = 1 + mix(seed^salt, k) % (V-1). */

@@ -29,7 +29,7 @@ EXPORTS = [
     "ka_ctc_best_path_batch_enqueue_f32", "ka_batch_finish", "ka_engine_set_profiling",
     "ka_engine_last_kernel_ms", "ka_log_softmax_f32", "ka_hash_logprobs_f32", "ka_hash_labels_i32",
     "ka_hash_logprobs_batch_f32", "ka_hash_labels_batch_i32", "ka_engine_set_mode", "ka_lstm_step_f32",
-    "ka_lstm_layer_f32",
+    "ka_lstm_layer_f32", "ka_window_energy_f32", "ka_stft_frames_f32", "ka_power_f32", "ka_power_to_db_f32",
 ]
 
 
@@ -98,6 +98,14 @@ def load_library():
     L.ka_lstm_layer_f32.argtypes = [vp, i64, vp, vp, i64, vp, vp, i32, i32, vp]
     L.ka_lstm_step_f32.restype = ctypes.c_int
     L.ka_lstm_step_f32.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, i64, vp, i64, i32, i32, vp]
+    L.ka_window_energy_f32.restype = ctypes.c_int
+    L.ka_window_energy_f32.argtypes = [vp, i64, i32, vp, vp]
+    L.ka_stft_frames_f32.restype = ctypes.c_int
+    L.ka_stft_frames_f32.argtypes = [vp, vp, vp, vp, i32, i64, i32, i32, vp, vp, i64, vp]
+    L.ka_power_f32.restype = ctypes.c_int
+    L.ka_power_f32.argtypes = [vp, i64, vp, i64, i64, i32, vp]
+    L.ka_power_to_db_f32.restype = ctypes.c_int
+    L.ka_power_to_db_f32.argtypes = [vp, i64, i32, vp, i32, i64, ctypes.c_float, vp, vp]
     L.ka_hash_logprobs_f32.restype = ctypes.c_int
     L.ka_hash_logprobs_f32.argtypes = [vp, i64, i32, i64, u64, vp]
     L.ka_hash_labels_i32.restype = ctypes.c_int

@@ -518,6 +518,55 @@ int ka_lstm_layer_f32(const float *gin, int64_t ldg, const float *w_hh, float *o
     return KA_OK;
 }
 
+int ka_window_energy_f32(const float *x, int64_t n_windows, int32_t window, float *out, void *stream)
+{
+    if (!x || !out || n_windows < 0) return fail(KA_ERR_BAD_ARGS, "ka_window_energy_f32: bad arguments");
+    if (window != 256) return fail(KA_ERR_BAD_ARGS, "ka_window_energy_f32: the summation order is NumPy's for windows of 256 samples only");
+    if (n_windows == 0) return KA_OK;
+    const int64_t blocks = (n_windows + 15) / 16;
+    if (blocks > 0x7fffffff) return fail(KA_ERR_BAD_ARGS, "ka_window_energy_f32: too many windows");
+    hipLaunchKernelGGL(ka::window_energy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n_windows, out);
+    KA_HIP(hipGetLastError());
+    return KA_OK;
+}
+
+int ka_stft_frames_f32(const float *y, const int64_t *seg_start, const int64_t *seg_len, const int64_t *frame_off, int32_t nseg,
+                       int64_t max_frames, int32_t n_fft, int32_t hop, const float *window, float *frames, int64_t ld, void *stream)
+{
+    if (!y || !seg_start || !seg_len || !frame_off || !window || !frames || nseg < 0 || n_fft < 2 || hop < 1 || ld < n_fft || max_frames < 0)
+        return fail(KA_ERR_BAD_ARGS, "ka_stft_frames_f32: bad arguments");
+    if (nseg == 0 || max_frames == 0) return KA_OK;
+    if (nseg > 65535) return fail(KA_ERR_BAD_ARGS, "ka_stft_frames_f32: more than 65535 segments in one call");
+    const unsigned gx = (unsigned)std::min<int64_t>(max_frames, 4096);
+    hipLaunchKernelGGL(ka::stft_frames_kernel, dim3(gx, (unsigned)nseg), dim3(256), 0, (hipStream_t)stream, y, seg_start, seg_len,
+                       frame_off, n_fft, hop, window, frames, ld);
+    KA_HIP(hipGetLastError());
+    return KA_OK;
+}
+
+int ka_power_f32(const float *reim, int64_t ld_in, float *power, int64_t ld_out, int64_t n, int32_t nf, void *stream)
+{
+    if (!reim || !power || n < 0 || nf < 1 || ld_in < 2 * (int64_t)nf || ld_out < nf) return fail(KA_ERR_BAD_ARGS, "ka_power_f32: bad arguments");
+    if (n == 0) return KA_OK;
+    const unsigned blocks = (unsigned)std::min<int64_t>((n * nf + 255) / 256, 65536);
+    hipLaunchKernelGGL(ka::power_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reim, ld_in, power, ld_out, n, nf);
+    KA_HIP(hipGetLastError());
+    return KA_OK;
+}
+
+int ka_power_to_db_f32(float *x, int64_t ld, int32_t cols, const int64_t *frame_off, int32_t nseg, int64_t max_frames, float top_db,
+                       float *segmax, void *stream)
+{
+    if (!x || !frame_off || !segmax || nseg < 0 || cols < 1 || ld < cols || max_frames < 0) return fail(KA_ERR_BAD_ARGS, "ka_power_to_db_f32: bad arguments");
+    if (nseg == 0 || max_frames == 0) return KA_OK;
+    if (nseg > 65535) return fail(KA_ERR_BAD_ARGS, "ka_power_to_db_f32: more than 65535 segments in one call");
+    const unsigned gx = (unsigned)std::min<int64_t>((max_frames * cols + 255) / 256, 256);
+    hipLaunchKernelGGL(ka::power_to_db_kernel, dim3(gx, (unsigned)nseg), dim3(256), 0, (hipStream_t)stream, x, ld, cols, frame_off, segmax);
+    hipLaunchKernelGGL(ka::db_floor_kernel, dim3(gx, (unsigned)nseg), dim3(256), 0, (hipStream_t)stream, x, ld, cols, frame_off, segmax, top_db);
+    KA_HIP(hipGetLastError());
+    return KA_OK;
+}
+
 int ka_hash_logprobs_batch_f32(float *dev_log_probs, int32_t n, int64_t T, int32_t V, int64_t ld, int64_t lattice_stride,
                                uint64_t seed0, void *stream)
 {
