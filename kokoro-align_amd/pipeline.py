@@ -244,12 +244,24 @@ def _swap_ext(files, old, new):
 
 def process_alignment(dataset, audio_files, metadata_file, model=None, remove_wordsep=False, device=None,
                       host_softmax=False, verbose=True):
-    """Given `<x>.mp3` names whose `<x>.mfcc.npz`, `<x>.split.txt`, `<x>.voca.txt` exist (made by the
-    reference's upstream stages), run predict -> best_path -> align -> combine_files with
-    skip-if-exists, all lattices of the dataset in one DP launch."""
+    """Given `<x>.mp3` names whose `<x>.voca.txt` exist (made by the reference's upstream stages), run
+    split_audio -> predict -> best_path -> align -> combine_files with skip-if-exists (run_example.py:205-275),
+    all lattices of the dataset in one DP launch.  The split_audio stage (run_example.py:205-218) runs where
+    `<x>.split.txt` / `<x>.mfcc.npz` are missing and needs the decoded audio as `<x>.wav` (16-bit PCM) or
+    `<x>.npy` next to the mp3 name: audio decoding is not part of this package."""
     say = print if verbose else (lambda *a, **k: None)
     mfcc = _swap_ext(audio_files, '.mp3', '.mfcc.npz')
     split = _swap_ext(audio_files, '.mp3', '.split.txt')
+    for af, sf, mf in zip(audio_files, split, mfcc):
+        if os.path.exists(sf) and os.path.exists(mf):
+            say(f'Skip converting {af} to MFCC')
+            continue
+        decoded = [f for f in _swap_ext([af], ".mp3", ".wav") + _swap_ext([af], ".mp3", ".npy") if os.path.exists(f)]
+        if not decoded:
+            raise FileNotFoundError(f'{sf} / {mf} are missing and there is no decoded audio ({af[:-4]}.wav or .npy) to make them from')
+        say(f'Converting {decoded[0]} to MFCC')
+        from .preprocess import split_audio
+        split_audio(decoded[0], sf, mf)
     voca = _swap_ext(audio_files, '.mp3', '.voca.txt')
     logits = _swap_ext(audio_files, '.mp3', '.logits.npz')
     greed = _swap_ext(audio_files, '.mp3', '.greed.txt')

@@ -114,3 +114,39 @@ def test_split_audio_writes_the_reference_file_formats(tmp_path):
     assert open(str(tmp_path / "ch02.split.txt")).read() == open(seg).read()
     with pytest.raises(ValueError):
         P.split_audio(str(tmp_path / "x.mp3"), seg, mf)
+
+
+def test_stage_runner_starts_from_the_waveform(tmp_path):
+    """run_example.py:205-275 from the split_audio stage on: decoded audio + voca.txt -> split.txt, mfcc.npz,
+    logits, best_path, align.txt, metadata; a second run skips every stage."""
+    import torch
+    from golden_util import g4
+    from kokoro_align_amd import pipeline
+    from kokoro_align_amd.model import AudioToChar
+    torch.manual_seed(5)
+    model = AudioToChar().cuda().eval()
+    cases = g6()["cases"]
+    audio_files = []
+    for i in (0, 1):
+        c = cases[i]
+        base = str(tmp_path / f"ch{i:02d}")
+        np.save(base + ".npy", F.hash_waveform(c["n"], c["seed"], c["pieces"]))
+        with open(base + ".voca.txt", "wt") as f:
+            f.write(g4()["voca_txt"])
+        audio_files.append(base + ".mp3")
+    meta = str(tmp_path / "out" / "ds.metadata.txt")
+    pipeline.process_alignment("ds", audio_files, meta, model=model, remove_wordsep=False, verbose=False)
+    par = g6()["parameters"]
+    for i, af in zip((0, 1), audio_files):
+        base = af[:-4]
+        ends = [int(v) * par["window_size"] for v in cases[i]["split_points"]] + [cases[i]["n"]]
+        assert [int(l) for l in open(base + ".split.txt").read().split()] == ends
+        with np.load(base + ".mfcc.npz") as f:
+            assert len(f["indices"]) == len(ends)
+        assert len(open(base + ".align.txt").read().splitlines()) == len(ends)
+    assert os.path.exists(meta)
+    before = {f: os.path.getmtime(f) for f in [meta] + [a[:-4] + e for a in audio_files for e in (".split.txt", ".mfcc.npz", ".best_path.npz")]}
+    pipeline.process_alignment("ds", audio_files, meta, model=None, remove_wordsep=False, verbose=False)
+    assert before == {f: os.path.getmtime(f) for f in before}
+    with pytest.raises(FileNotFoundError):
+        pipeline.process_alignment("ds", [str(tmp_path / "nothing.mp3")], meta + "2", model=model, verbose=False)
