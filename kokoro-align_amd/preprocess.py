@@ -97,9 +97,16 @@ def get_split_points(x, minimum_silent_frames, minimum_split_distance, maximum_s
     silent_threshold = (np.max(mX) + np.min(mX)) / 2
     while True:
         voiced = mX > silent_threshold
-        for s, e in get_silent_ranges(voiced):
-            if e - s < minimum_silent_frames:
-                voiced[s:e] = True                 # fill short silences
+        # fill short silences (preprocess.py:63-65 does it range by range; the ranges are disjoint, so marking
+        # starts +1 / ends -1 and taking the running sum fills them all at once: a recording of 8 hours has
+        # ~10^4 ranges and this loop runs up to 9 times)
+        r = get_silent_ranges(voiced)
+        short = (r[:, 1] - r[:, 0]) < minimum_silent_frames
+        if short.any():
+            mark = np.zeros(num_frames + 1, dtype=np.int32)
+            mark[r[short, 0]] = 1
+            mark[r[short, 1]] -= 1
+            voiced |= np.cumsum(mark[:-1]) > 0
         silent_ranges = get_silent_ranges(voiced)
         silent_points = (silent_ranges[:, 0] + silent_ranges[:, 1]) // 2   # split in the centre of a silence
         split_distance = np.append(silent_points, num_frames) - np.insert(silent_points, 0, 0)
@@ -108,20 +115,62 @@ def get_split_points(x, minimum_silent_frames, minimum_split_distance, maximum_s
         minimum_silent_frames *= 0.5
         if minimum_silent_frames < 0.05:
             raise ValueError("Audio cannot be split into")
-    while len(silent_points):                      # merge short pieces into a neighbour
-        split_distance = np.append(silent_points, num_frames) - np.insert(silent_points, 0, 0)
-        i = np.argmin(split_distance)
-        if split_distance[i] > minimum_split_distance:
+    return _merge_short_pieces(silent_points, num_frames, minimum_split_distance)
+
+
+def _merge_short_pieces(points, num_frames, minimum_split_distance):
+    """preprocess.py:81-95: while the shortest piece (first one among equals) is not longer than the minimum, remove
+    one of its end points - the only one it has at either end of the recording, otherwise the one towards its shorter
+    neighbour (towards the later one when they are equal).  The reference rebuilds and scans the whole distance array
+    for every removal (quadratic: 50 ms for 8 hours of audio); here the pieces sit in a doubly linked list with a heap
+    of (length, position) - the same removals in the same order."""
+    import heapq
+    k = len(points)
+    if k == 0:
+        return points
+    bounds = [0] + [int(p) for p in points] + [int(num_frames)]       # piece j = [bounds[j], bounds[j+1])
+    npieces = k + 1
+    left = list(range(-1, npieces - 1))                                # neighbouring live pieces
+    right = list(range(1, npieces + 1))
+    start = bounds[:-1]
+    end = bounds[1:]
+    alive = [True] * npieces
+    heap = [(end[j] - start[j], start[j], j) for j in range(npieces)]
+    heapq.heapify(heap)
+    live = npieces
+    while live > 1:
+        d, st, j = heap[0]
+        if not alive[j] or st != start[j] or d != end[j] - start[j]:
+            heapq.heappop(heap)                                        # stale entry
+            continue
+        if d > minimum_split_distance:
             break
-        if i == 0:
-            silent_points = np.delete(silent_points, i)
-        elif i == len(silent_points):
-            silent_points = np.delete(silent_points, len(silent_points) - 1)
-        elif split_distance[i - 1] < split_distance[i + 1]:
-            silent_points = np.delete(silent_points, i - 1)
+        lj, rj = left[j], right[j]
+        if lj < 0:
+            other = rj                                                 # first piece: drop its right end point
+        elif rj >= npieces:
+            other = lj                                                 # last piece: drop its left end point
+        elif end[lj] - start[lj] < end[rj] - start[rj]:
+            other = lj
         else:
-            silent_points = np.delete(silent_points, i)
-    return silent_points
+            other = rj
+        a, b = (other, j) if other == lj else (j, other)               # a is the left one of the two pieces that fuse
+        heapq.heappop(heap)
+        end[a] = end[b]
+        alive[b] = False
+        right[a] = right[b]
+        if right[b] < npieces:
+            left[right[b]] = a
+        live -= 1
+        heapq.heappush(heap, (end[a] - start[a], start[a], a))
+    out = []
+    j = 0
+    while right[j] < npieces:
+        out.append(end[j])
+        j = right[j]
+    return np.asarray(out, dtype=np.asarray(points).dtype)
+
+
 
 
 # ----------------------------------------------------------------------------------------

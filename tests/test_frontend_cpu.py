@@ -55,3 +55,35 @@ def test_mfcc_restatement_is_self_consistent():
     a = F.mfcc(y) @ F.dct_matrix(40, 40).T
     b = F.mfcc(10.0 * y) @ F.dct_matrix(40, 40).T
     assert np.allclose(b - a, 20.0, atol=1e-9)            # nothing near the floor for white noise
+
+
+def test_product_merge_of_short_pieces_is_the_reference_order():
+    """kokoro_align_amd.preprocess replaces the reference's quadratic merge loop (preprocess.py:81-95) by a heap over a
+    linked list; the removals must be the same, ties included (host logic: no GPU needed)."""
+    import importlib
+    P = importlib.import_module("kokoro_align_amd.preprocess")
+
+    def loop(points, num_frames, m):          # the loop as oracle/frontend_oracle.py restates it
+        points = np.asarray(points)
+        while len(points):
+            dist = np.append(points, num_frames) - np.insert(points, 0, 0)
+            i = np.argmin(dist)
+            if dist[i] > m:
+                break
+            if i == 0:
+                points = np.delete(points, i)
+            elif i == len(points):
+                points = np.delete(points, len(points) - 1)
+            elif dist[i - 1] < dist[i + 1]:
+                points = np.delete(points, i - 1)
+            else:
+                points = np.delete(points, i)
+        return points
+
+    rng = np.random.default_rng(8)
+    for _ in range(1500):
+        k = int(rng.integers(0, 60))
+        n = int(rng.integers(k + 1, 500))
+        pts = np.sort(rng.choice(np.arange(1, n), size=min(k, n - 1), replace=False)) if k else np.array([], dtype=np.int64)
+        m = float(rng.uniform(0, 80))
+        assert list(loop(pts, n, m)) == list(P._merge_short_pieces(pts, n, m))
