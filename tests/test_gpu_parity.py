@@ -314,6 +314,35 @@ def test_full_occupancy_batch_sampled_against_the_oracle(ka):
         assert np.array_equal(batch.best_scores[i].cpu().numpy().view(np.int32), want[2].view(np.int32)), i
 
 
+@pytest.mark.parametrize("mm", [3, 4])
+def test_full_occupancy_batch_with_label_zero_and_strided_rows(ka, mm):
+    """The same at 4096 lattices for the kernel instances the previous test does not reach: transcripts that contain
+    label 0 (the zero-label instances run beside the ordinary ones), V = 39 columns in rows of 64 floats, max_move 3
+    and 4, beam 700."""
+    import torch
+    B, T, V, S, LD = 4096, 3000, 39, 350, 64
+    lib = ka.load_library()
+    lps = torch.full((B, T, LD), float("nan"), dtype=torch.float32, device="cuda")     # the padding columns are never read
+    labs = torch.empty((B, S), dtype=torch.int32, device="cuda")
+    assert lib.ka_hash_logprobs_batch_f32(lps.data_ptr(), B, T, V, LD, T * LD, 9500, None) == 0
+    assert lib.ka_hash_labels_batch_i32(labs.data_ptr(), B, S, V, S, 9500, None) == 0
+    labs[::2, ::7] = 0            # every other lattice has label 0 in its transcript
+    torch.cuda.synchronize()
+    from kokoro_align_amd.align import DeviceBatch
+    batch = DeviceBatch([lps[i][:, :V] for i in range(B)], [labs[i] for i in range(B)], 700, mm)
+    batch.run()
+    batch.run()
+    sample = sorted(set([0, 1, B - 2, B - 1] + np.random.default_rng(5).integers(0, B, size=24).tolist()))
+    for i in sample:
+        lab = O.hash_labels(S, V, 9500 + i)
+        if i % 2 == 0:
+            lab[::7] = 0
+        want = O.ctc_best_path_c(O.hash_logprobs(T, V, 9500 + i), lab, 700, mm)
+        assert np.array_equal(batch.path[i].cpu().numpy(), want[0]), i
+        assert np.array_equal(batch.best_labels[i].cpu().numpy(), want[1]), i
+        assert np.array_equal(batch.best_scores[i].cpu().numpy().view(np.int32), want[2].view(np.int32)), i
+
+
 def test_cfg5_long_form_band(ka):
     """BASELINE configs[4] with the default band: T=500000 x V=64, S=50000 (L=100001); 128 MB of back-pointers."""
     import torch
