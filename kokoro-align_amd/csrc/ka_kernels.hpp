@@ -497,7 +497,6 @@ __device__ __forceinline__ void frame_scores(f32x2 (&P)[8], float h1, float h2, 
     P[2 * G] = mb + e00;
     E[G][0] = lds_col(next_row, la[2 * G]);
     E[G][1] = lds_col(next_row, la[2 * G + 1]);
-    __builtin_amdgcn_sched_barrier(0);   // as in frame_cells: keep the groups in program order
     if constexpr (G > 0) frame_scores<M, ZL, G - 1>(P, h1, h2, h3, E, vz, e00, la, next_row);
 }
 
