@@ -1491,6 +1491,7 @@ __global__ __launch_bounds__(64) void backtrace_rc_kernel(const Lattice *__restr
     const auto uni = [](uint64_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v); };
     uint32_t q0 = uni(((uint64_t)L * t0) / T), r0 = uni(((uint64_t)L * t0) % T);
     const uint32_t D32 = uni(((uint64_t)L * kCkFrames) / T), R32 = uni(((uint64_t)L * kCkFrames) % T);
+    const float inv_T = 1.0f / (float)T;
 
     for (;;) {
         const int n = (int)(T - t0 < (uint32_t)kCkFrames ? T - t0 : (uint32_t)kCkFrames);
@@ -1543,9 +1544,17 @@ __global__ __launch_bounds__(64) void backtrace_rc_kernel(const Lattice *__restr
         // floor(L*(t0+f)/T) of all frames of the chunk at once, lane f <-> frame f (r0 + 33*dr < 34*T: the host
         // keeps T below 2^26 in this form), and the frames after which it moves as a bit mask: the common frame
         // then pays one s_bitcmp1 + s_cbranch for the band instead of a scalar Bresenham step
+        // (x / T for x < 35*T < 2^32 by a float estimate and one correction each way: 7 vector instructions instead of
+        //  the ~20 of a general 32-bit division, twice per chunk; lanes above 33 may wrap - their results are not used)
+        const auto div_T = [&](uint32_t x) {
+            uint32_t qe = (uint32_t)((float)x * inv_T);
+            qe -= (qe * T > x) ? 1u : 0u;
+            qe += (x - qe * T >= T) ? 1u : 0u;
+            return qe;
+        };
         const uint32_t qnum = r0 + (uint32_t)lane * dr;
-        const uint32_t qa = q0 + (uint32_t)lane * dq + qnum / T;
-        const uint32_t qb = q0 + (uint32_t)(lane + 1) * dq + (qnum + dr) / T;
+        const uint32_t qa = q0 + (uint32_t)lane * dq + div_T(qnum);
+        const uint32_t qb = q0 + (uint32_t)(lane + 1) * dq + div_T(qnum + dr);
         const uint32_t moves = (uint32_t)__builtin_amdgcn_ballot_w64(qa != qb);   // bit f: frame f+1's band differs from frame f's
         uint64_t mask_b = 0, mask_l = 0;
 #pragma unroll
