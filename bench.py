@@ -183,7 +183,7 @@ def main():
     single = None
     if rank == 0:
         batch.engine.set_mode("auto")
-        one = DeviceBatch([lps[0]], [labs[0]], BEAM, MAX_MOVE)   # 1 lattice: KA_MODE_AUTO picks the 4-wavefront form
+        one = DeviceBatch([lps[0]], [labs[0]], BEAM, MAX_MOVE)   # 1 lattice, KA_MODE_AUTO
         one.engine.set_profiling(True)
         one.run()
         t1 = time.perf_counter()
@@ -198,7 +198,7 @@ def main():
         value = frames_per_step * args.steps / elapsed
         fwd_b, job_b, wbar, survey_fwd_b = algorithmic_bytes_per_frame()
         fwd_s = float(np.mean(fwd_ms)) * 1e-3
-        checkpointed = (args.mode == "auto" and B > 512) or args.mode == "wave"   # the form KA_MODE_AUTO takes at this batch size
+        checkpointed = args.mode in ("auto", "wave")   # KA_MODE_AUTO is the checkpointed form at every batch size
         if not checkpointed:     # every back-pointer stored: SURVEY.md 8d's bytes are this form's own
             fwd_b = survey_fwd_b
             job_b = survey_fwd_b + 12.25 + 4.0 * V / 2

@@ -105,9 +105,9 @@ int ka_batch_finish(ka_engine *e, float *total_score, int32_t *status);
  *                       not all finite are redone by the exact kernels in the same call; a call with a lattice of
  *                       2^26 frames or more runs entirely in the exact form.
  *   KA_MODE_WAVE_EXACT  one wavefront per lattice, every back-pointer stored (2 bits per band cell).
- *   KA_MODE_WORKGROUP   four wavefronts per lattice with an LDS hand-off per frame (latency: a single file, a
- *                       book's few dozen chapters); back-pointers stored.
- *   KA_MODE_AUTO        (default) WORKGROUP up to 512 lattices per call, WAVE above.
+ *   KA_MODE_WORKGROUP   four wavefronts per lattice with an LDS hand-off per frame; back-pointers stored.  The
+ *                       shortest forward pass for one lattice, but WAVE's two kernels together are faster.
+ *   KA_MODE_AUTO        (default) WAVE.
  * Results are identical in every form. */
 #define KA_MODE_AUTO 0
 #define KA_MODE_WAVE 1

@@ -36,7 +36,10 @@ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 // KA_MODE_AUTO: up to this many lattices per call use the 4-wavefront form.  Measured on cfg2 lattices
 // (tools/sweep_modes.sh): 20.8 vs 23.0 ms at 256 lattices, 23.2 vs 23.9 ms at 512, 30.3 vs 24.1 ms at 1024
 // (four-wavefront form vs checkpointed one-wavefront form).
-constexpr int32_t kAutoWorkgroupMaxLattices = 512;
+// KA_MODE_AUTO never picks the 4-wavefront form any more: since the checkpointed forward kernel lost a third of its
+// instructions a lone wavefront does a cfg2 lattice in 11.2 + 8.2 ms against 18.7 + 1.4 ms for four wavefronts with
+// stored back-pointers, and it stays ahead at every batch size (64: 19.9 vs 20.4 ms, 512: 21.4 vs 23.1 ms).
+constexpr int32_t kAutoWorkgroupMaxLattices = 0;
 
 struct Shape {
     int64_t T, S, L, W;
