@@ -178,6 +178,12 @@ def main():
         ok = bool(np.array_equal(batch.path[0].cpu().numpy(), g3["path"]))
         ends = torch.stack([p[-1] for p in batch.path[: min(B, 64)]]).cpu().numpy()
         ok = ok and bool((ends == 2 * S).all())
+        # and, without any reference, on a spread of lattices: the float32 chain of the per-frame scores along the
+        # returned path must be the forward pass's best cumulative score bit for bit (a path that is not THE best
+        # path of its lattice misses it; this is what caught a store hazard that left every end position right)
+        pick = sorted(set(np.linspace(0, B - 1, num=min(B, 256), dtype=np.int64).tolist()))
+        chain = np.add.accumulate(torch.stack([batch.best_scores[i] for i in pick]).cpu().numpy(), axis=1, dtype=np.float32)[:, -1]
+        ok = ok and bool(np.array_equal(chain.view(np.int32), np.asarray(batch.total, np.float32)[pick].view(np.int32)))
 
     # single-lattice latency (the serial T-chain; one wavefront busy on the whole chip)
     single = None

@@ -306,6 +306,10 @@ def test_full_occupancy_batch_sampled_against_the_oracle(ka):
     batch = DeviceBatch([lps[i] for i in range(B)], [labs[i] for i in range(B)])
     batch.run()
     batch.run()
+    # every lattice, without the oracle: the float32 chain of the per-frame scores along the returned path is the
+    # forward pass's best cumulative score, bit for bit (each score on the best path IS fl(previous + emission))
+    chain = np.add.accumulate(torch.stack(batch.best_scores).cpu().numpy(), axis=1, dtype=np.float32)[:, -1]
+    assert np.array_equal(chain.view(np.int32), np.asarray(batch.total, np.float32).view(np.int32))
     sample = sorted(set([0, B - 1] + np.random.default_rng(4).integers(0, B, size=30).tolist()))
     for i in sample:
         want = O.ctc_best_path_c(O.hash_logprobs(T, V, 9000 + i), O.hash_labels(S, V, 9000 + i))
