@@ -33,4 +33,12 @@ for rep in range(3):
         elif not (np.array_equal(batch.best_labels[i].cpu().numpy(), want[1])
                   and np.array_equal(batch.best_scores[i].cpu().numpy().view(np.int32), want[2].view(np.int32))):
             bad.append((i, "labels/scores differ"))
-    print(f"rep {rep} mode={mode} B={B} T={T}: ends wrong: {nbad_end} (idx {np.nonzero(ends != 2 * S)[0][:8].tolist()}); sample mismatches: {bad}")
+    # every lattice, reference-free: float32 chain of best_scores along the path == the forward pass's total
+    off = []
+    for a in range(0, B, 512):
+        sc = torch.stack(batch.best_scores[a:a + 512]).cpu().numpy()
+        chain = np.add.accumulate(sc, axis=1, dtype=np.float32)[:, -1]
+        tot = np.asarray(batch.total, np.float32)[a:a + 512]
+        off += (a + np.nonzero(chain.view(np.int32) != tot.view(np.int32))[0]).tolist()
+    print(f"rep {rep} mode={mode} B={B} T={T}: ends wrong: {nbad_end} (idx {np.nonzero(ends != 2 * S)[0][:8].tolist()}); "
+          f"chain != total on {len(off)} lattices {off[:8]}; sample mismatches: {bad}")
