@@ -347,6 +347,38 @@ def test_full_occupancy_batch_with_label_zero_and_strided_rows(ka, mm):
         assert np.array_equal(batch.best_scores[i].cpu().numpy().view(np.int32), want[2].view(np.int32)), i
 
 
+def test_cfg2_batch_at_full_size_properties(ka):
+    """1024 lattices of BASELINE configs[1] (T = 50 000, V = 64, S = 5 000, beam 1000, max_move 4), every one checked
+    through size-independent properties: the path ends on the trailing blank, never goes back and never moves more
+    than 3, best_labels is the expanded transcript read along the path, best_scores are the log-probs read at those
+    labels, and their float32 running sum is the forward pass's best cumulative score bit for bit."""
+    import torch
+    B, T, V, S = 1024, 50000, 64, 5000
+    lib = ka.load_library()
+    lps = torch.empty((B, T, V), dtype=torch.float32, device="cuda")
+    labs = torch.empty((B, S), dtype=torch.int32, device="cuda")
+    assert lib.ka_hash_logprobs_batch_f32(lps.data_ptr(), B, T, V, V, T * V, 100, None) == 0
+    assert lib.ka_hash_labels_batch_i32(labs.data_ptr(), B, S, V, S, 100, None) == 0
+    torch.cuda.synchronize()
+    from kokoro_align_amd.align import DeviceBatch
+    batch = DeviceBatch([lps[i] for i in range(B)], [labs[i] for i in range(B)], 1000, 4)
+    batch.run()
+    path = torch.stack(batch.path)                       # [B, T] on the device
+    assert bool((path[:, -1] == 2 * S).all()) and bool((path[:, 0] >= 0).all()) and bool((path[:, 0] <= 3).all())
+    step = path[:, 1:] - path[:, :-1]
+    assert bool((step >= 0).all()) and bool((step <= 3).all())
+    expanded = torch.zeros((B, 2 * S + 1), dtype=torch.int32, device="cuda")
+    expanded[:, 1::2] = labs
+    want_labels = torch.gather(expanded, 1, path.long())
+    got_labels = torch.stack(batch.best_labels)
+    assert bool((got_labels == want_labels).all())
+    want_scores = torch.gather(lps, 2, got_labels.long().unsqueeze(2)).squeeze(2)
+    got_scores = torch.stack(batch.best_scores)
+    assert bool((got_scores.view(torch.int32) == want_scores.view(torch.int32)).all())
+    chain = np.add.accumulate(got_scores.cpu().numpy(), axis=1, dtype=np.float32)[:, -1]
+    assert np.array_equal(chain.view(np.int32), np.asarray(batch.total, np.float32).view(np.int32))
+
+
 def test_cfg5_long_form_band(ka):
     """BASELINE configs[4] with the default band: T=500000 x V=64, S=50000 (L=100001); 128 MB of back-pointers."""
     import torch
