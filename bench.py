@@ -87,6 +87,23 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start one rank per GPU as a CHILD process (never an exec,
+        # and before anything here has touched the GPU), relay rank 0's JSON line and the exit code
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+        lines = [ln for ln in proc.stdout.decode("utf-8", "replace").splitlines() if ln.startswith("{")]
+        if lines:
+            print(lines[-1], flush=True)
+        sys.exit(proc.returncode if proc.returncode else (0 if lines else 1))
+
     # stdout must carry exactly ONE JSON line: native libraries (RCCL prints a version banner) write to
     # fd 1 directly, so point fd 1 at stderr until the result is printed
     sys.stdout.flush()
@@ -101,9 +118,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     # rehearsal knobs (never set by the driver): several ranks on ONE GPU over gloo, to exercise the
     # multi-rank control flow on a single-GPU box

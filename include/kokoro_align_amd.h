@@ -32,6 +32,8 @@ extern "C" {
 #define KA_ERR_HIP (-3)       /* HIP runtime error, text in ka_last_error() */
 #define KA_ERR_NOMEM (-4)
 #define KA_ERR_BAD_LABEL (-5) /* label outside [0,V): reference raises IndexError at align.py:77 */
+#define KA_ERR_NAN (-6)       /* a log-prob is NaN: the reference's np.argmax treats NaN as the maximum (align.py:83); that
+                                 is not reproduced - the lattice is rejected (fast path, V <= 64, band <= 1009 or tiled form) */
 
 /* where the caller's buffers live */
 #define KA_MEM_HOST 0

@@ -20,6 +20,7 @@ KA_ERR_BAD_ARGS = -2
 KA_ERR_HIP = -3
 KA_ERR_NOMEM = -4
 KA_ERR_BAD_LABEL = -5
+KA_ERR_NAN = -6
 KA_MEM_HOST = 0
 KA_MEM_DEVICE = 1
 
@@ -133,6 +134,8 @@ def check(rc, what):
     if rc == KA_ERR_BAD_LABEL:
         # reference: log_probs[i, labels[v]] at kokoro_align/align.py:77
         raise IndexError(f"{what}: label out of bounds for the vocabulary axis ({msg})")
+    if rc == KA_ERR_NAN:
+        raise ValueError(f"{what}: log_probs contain NaN ({msg})")
     if rc == KA_ERR_BAD_ARGS:
         raise ValueError(f"{what}: {msg}")
     if rc == KA_ERR_NOMEM:

@@ -33,9 +33,25 @@ int fail(int code, const std::string &msg)
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
-// KA_MODE_AUTO: up to this many lattices per call use the 4-wavefront form.  Measured on cfg2 lattices
-// (tools/sweep_modes.sh): 20.8 vs 23.0 ms at 256 lattices, 23.2 vs 23.9 ms at 512, 30.3 vs 24.1 ms at 1024
-// (four-wavefront form vs checkpointed one-wavefront form).
+// The engine works on ITS device and leaves the caller's current device (which PyTorch shares, per thread) as it
+// found it, on every exit path.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t enter(int dev)
+    {
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess || prev == dev) return e;
+        e = hipSetDevice(dev);
+        switched = e == hipSuccess;
+        return e;
+    }
+    ~DeviceGuard()
+    {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
 // KA_MODE_AUTO never picks the 4-wavefront form any more: since the checkpointed forward kernel lost a third of its
 // instructions a lone wavefront does a cfg2 lattice in 11.2 + 8.2 ms against 18.7 + 1.4 ms for four wavefronts with
 // stored back-pointers, and it stays ahead at every batch size (64: 19.9 vs 20.4 ms, 512: 21.4 vs 23.1 ms).
@@ -168,7 +184,8 @@ int ka_engine_create(int32_t device, ka_engine **out)
     KA_HIP(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev)
         return fail(KA_ERR_BAD_ARGS, "ka_engine_create: device " + std::to_string(device) + " of " + std::to_string(ndev));
-    KA_HIP(hipSetDevice(device));
+    DeviceGuard guard;
+    KA_HIP(guard.enter(device));
     ka_engine *e = new ka_engine();
     e->device = device;
     for (int i = 0; i < 5; ++i) {
@@ -185,7 +202,8 @@ int ka_engine_create(int32_t device, ka_engine **out)
 void ka_engine_destroy(ka_engine *e)
 {
     if (!e) return;
-    (void)hipSetDevice(e->device);
+    DeviceGuard guard;
+    (void)guard.enter(e->device);
     (void)hipDeviceSynchronize();
     if (e->ws) (void)hipFree(e->ws);
     if (e->pin) (void)hipHostFree(e->pin);
@@ -197,7 +215,8 @@ void ka_engine_destroy(ka_engine *e)
 int ka_engine_reserve(ka_engine *e, size_t workspace_bytes)
 {
     if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
-    KA_HIP(hipSetDevice(e->device));
+    DeviceGuard guard;
+    KA_HIP(guard.enter(e->device));
     return ensure_ws(e, workspace_bytes);
 }
 
@@ -249,7 +268,8 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
     if (n < 0 || (n > 0 && (!log_probs || !T || !ld || !labels || !S || !best_path || !best_labels || !best_scores)))
         return fail(KA_ERR_BAD_ARGS, "batch: NULL array argument");
     if (mem != KA_MEM_HOST && mem != KA_MEM_DEVICE) return fail(KA_ERR_BAD_ARGS, "mem must be KA_MEM_HOST or KA_MEM_DEVICE");
-    KA_HIP(hipSetDevice(e->device));
+    DeviceGuard guard;
+    KA_HIP(guard.enter(e->device));
     e->n_last = n;
     e->stream_last = stream;
     e->have_times = false;
@@ -439,7 +459,8 @@ int ka_batch_finish(ka_engine *e, float *total_score, int32_t *status)
     if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
     if (!e->pending) return fail(KA_ERR_BAD_ARGS, "no batch enqueued");
     e->pending = false;
-    KA_HIP(hipSetDevice(e->device));
+    DeviceGuard guard;
+    KA_HIP(guard.enter(e->device));
     KA_HIP(hipStreamSynchronize(e->stream_last));
     if (e->profiling && e->n_last > 0) e->have_times = true;
     int first_bad = KA_OK;
@@ -451,6 +472,7 @@ int ka_batch_finish(ka_engine *e, float *total_score, int32_t *status)
             first_bad = m[0];
             g_err = "lattice " + std::to_string(i) + (m[0] == KA_ERR_EMPTY_BEAM ? ": no live state in the last frame (empty beam)"
                                                       : m[0] == KA_ERR_BAD_LABEL ? ": label outside [0, V)"
+                                                      : m[0] == KA_ERR_NAN       ? ": a log-prob is NaN"
                                                                                  : ": failed");
         }
     }

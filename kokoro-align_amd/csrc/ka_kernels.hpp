@@ -16,8 +16,9 @@
 //   * scores live in 16 VGPRs per lane; the three neighbours p-1..p-3 of a lane's first
 //     cells come from the previous lane with DPP wave_ror:1.
 //   * lane v of a "row" register holds lp[t, v] (V <= 64): one coalesced 256-B load per
-//     frame, prefetched 4 frames ahead; blank emission = readfirstlane, label emissions
-//     = 8 ds_bpermute per frame (no LDS memory, no bank conflicts).
+//     frame, prefetched 4 frames ahead; blank emission = readfirstlane; the 8 label emissions per
+//     lane are gathers lp[t, lab'[p]]: ds_bpermute on the row register in the exact / recompute /
+//     workgroup kernels, ds_read_b32 from an LDS copy of the row in the checkpointed forward kernel.
 //   * the band [lo,hi) is applied with 16 wave-uniform 64-bit lane masks (one per cell
 //     index) held in SGPRs and updated only when lo/hi move.
 // Three kernel forms:
@@ -54,6 +55,7 @@ typedef KA_GLOBAL const v4i_t *gci4_t;
 constexpr int kStatusOk = 0;
 constexpr int kStatusEmptyBeam = -1;
 constexpr int kStatusBadLabel = -5;
+constexpr int kStatusNaN = -6;      // a log-prob is NaN (the reference's np.argmax would treat it as a maximum: not reproduced)
 constexpr int kFlagZeroLabel = 1;   // meta flags: a transcript label is 0
 constexpr int kFlagExact = 2;       // meta flags: the checkpointed path declined this lattice (non-finite log-probs)
 
@@ -596,6 +598,7 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
 #pragma unroll
     for (int i = 0; i < 8; ++i) e[i] = bperm(la[i], rows[0]);
     e0[0] = first_lane(rows[0]);
+    float absum = __builtin_fabsf(rows[0]);   // NaN detector: sum over frames of |lp[t, lane]|
 
     const uint32_t *bp = reinterpret_cast<const uint32_t *>(d.bp);   // wave-uniform row base
     const uint32_t lane_store_off = (uint32_t)lane * 16u;   // back-pointers: [t/4][block][t%4] dwords
@@ -668,6 +671,7 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
                 if (dd < D - 1) row_wait<D - 1>(rows[(dd + 1) % D]); else row_wait<D - 2>(rows[(dd + 1) % D]);
                 const float rn = rows[(dd + 1) % D];
                 e0[(dd + 1) & 1] = first_lane(rn);
+                absum += __builtin_fabsf(rn);
                 // C. frame t
                 uint32_t word = 0;
                 frame_cells<M, ZL, 15>(sc, h1, h2, h3, e, vz, e0[dd & 1], mk, NINF, word, la, rn);
@@ -703,7 +707,8 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
         // one 16-byte store per lane per 4 frames.  saddr (uniform pointer to the group) + voffset
         // (lane*16): no per-lane 64-bit address registers
         const u32x4 words = {gw[0], gw[1], gw[2], gw[3]};
-        asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(lane_store_off), "v"(words), "s"(bp + (size_t)tb * 64) : "memory");
+        // (s_nop 1: a store wider than 64 bits reads its data registers for two more wait states, see forward_ck)
+        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(lane_store_off), "v"(words), "s"(bp + (size_t)tb * 64) : "memory");
     }
 
     // Drain the row prefetches that are still in flight (the last D frames prefetch clamped rows that are
@@ -713,6 +718,13 @@ __device__ __forceinline__ void forward_w16(const Lattice &d, int32_t *meta)
     for (int i = 0; i < D; ++i) row_wait<0>(rows[i]);
 
     int32_t *m = meta_of(meta, d.idx);
+    if (__builtin_amdgcn_ballot_w64((__builtin_bit_cast(uint32_t, absum) & 0x7fffffffu) > 0x7f800000u)) {   // a NaN log-prob
+        if (lane == 0) {
+            m[1] = -1;
+            atomicMin(&m[0], kStatusNaN);
+        }
+        return;
+    }
     // terminal state: the HIGHEST live position of frame T-1 (align.py:99-101)
     int best = -1;
     if (pres2) best = blk * 16 + ((31 - __clz((int)pres2)) >> 1);
@@ -922,8 +934,17 @@ __device__ __forceinline__ void forward_ck(const Lattice &d, int32_t *meta)
     // Every partial path score is bounded by the sum of all |lp|: if each column's sum stays below 1e30 nothing
     // can have overflowed and every live state has a finite score, so live <=> score > -inf.  Otherwise (an
     // infinity, a NaN, absurd magnitudes) hand the lattice to the exact kernels.
-    const bool ok = absum < 1e30f;
-    if (__builtin_amdgcn_ballot_w64(!ok)) {
+    // (integer test on the bits: the library is built with -fno-honor-nans, under which `!(absum < 1e30f)` is
+    //  lowered to an ordered compare that a NaN passes)
+    const uint32_t abits = __builtin_bit_cast(uint32_t, absum) & 0x7fffffffu;
+    if (__builtin_amdgcn_ballot_w64(abits > 0x7f800000u)) {   // NaN: an explicit error, no path
+        if (lane == 0) {
+            m[1] = -1;
+            atomicMin(&m[0], kStatusNaN);
+        }
+        return;
+    }
+    if (__builtin_amdgcn_ballot_w64(abits >= __builtin_bit_cast(uint32_t, 1e30f))) {
         if (lane == 0) atomicOr(&m[2], kFlagExact);
         return;
     }
@@ -1120,6 +1141,7 @@ __device__ __forceinline__ void forward_wg4(const Lattice &d, int32_t *meta)
     e[0][0] = bperm(la[0], rows[0]);
     e[0][1] = bperm(la[1], rows[0]);
     e0[0] = first_lane(rows[0]);
+    float absum = __builtin_fabsf(rows[0]);   // NaN detector (every wave loads every row)
 
     const uint32_t *bp = reinterpret_cast<const uint32_t *>(d.bp);
     const uint32_t store_off = (uint32_t)tid * 4u;       // [t/4][block = tid>>2][t%4 = tid&3] dwords: thread tid keeps frame tid&3
@@ -1193,6 +1215,7 @@ __device__ __forceinline__ void forward_wg4(const Lattice &d, int32_t *meta)
                 {
                     if (dd < D - 1) row_wait<D - 1>(rows[(dd + 1) % D]); else row_wait<D - 2>(rows[(dd + 1) % D]);   // as in forward_w16
                     const float rn = rows[(dd + 1) % D];
+                    absum += __builtin_fabsf(rn);
                     e[(dd + 1) & 1][0] = bperm(la[0], rn);
                     e[(dd + 1) & 1][1] = bperm(la[1], rn);
                     e0[(dd + 1) & 1] = first_lane(rn);
@@ -1263,13 +1286,19 @@ __device__ __forceinline__ void forward_wg4(const Lattice &d, int32_t *meta)
         const int o = __shfl_xor(best, off);
         best = o > best ? o : best;
     }
+    if (__builtin_amdgcn_ballot_w64((__builtin_bit_cast(uint32_t, absum) & 0x7fffffffu) > 0x7f800000u)) best = -2;   // a NaN log-prob
     if (lane == 0) s_best[wv] = best;
     __syncthreads();
     best = s_best[0];
 #pragma unroll
     for (int w = 1; w < 4; ++w) best = s_best[w] > best ? s_best[w] : best;
     int32_t *m = meta_of(meta, d.idx);
-    if (best < 0) {
+    if (s_best[0] == -2) {   // (all four waves see the same rows)
+        if (tid == 0) {
+            m[1] = -1;
+            atomicMin(&m[0], kStatusNaN);
+        }
+    } else if (best < 0) {
         if (tid == 0) {
             m[1] = -1;
             atomicMin(&m[0], kStatusEmptyBeam);
@@ -1816,8 +1845,8 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------
-// One whole LSTM layer, both directions, persistent: a 256-thread workgroup owns 32 sequences of one direction
-// for ALL their time steps.  The recurrent product h @ W_hh^T runs on the f32 MFMA (v_mfma_f32_32x32x2_f32,
+// One whole LSTM layer, both directions, persistent: a 256-thread workgroup owns 16 sequences of one direction
+// for ALL their time steps.  The recurrent product h @ W_hh^T runs on the f32 MFMA (v_mfma_f32_16x16x4_f32,
 // exact float32): wave w computes the four gates of hidden units [32w, 32w+32), and its 128 x 128 slice of
 // W_hh^T (64 KB) stays in registers for the whole kernel - 256 of the 512 VGPR/AGPRs a wave has at one
 // wave per SIMD - so no weight byte is read after start-up.  h lives in LDS (double-buffered, one barrier per

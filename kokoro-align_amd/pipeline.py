@@ -270,7 +270,7 @@ def process_alignment(dataset, audio_files, metadata_file, model=None, remove_wo
     on_device = {}
     missing = []
     for mf, lf, gf in zip(mfcc, logits, greed):
-        if os.path.exists(lf):
+        if os.path.exists(lf) and os.path.exists(gf):   # both outputs, like run_example.py:227
             say(f'Skip writing {lf}')
         else:
             if model is None:

@@ -487,6 +487,23 @@ def test_checkpointed_form_hands_over_what_it_cannot_do(ka):
         assert np.float32(total[i]).view(np.int32) == np.float32(w[3]).view(np.int32), i
 
 
+def test_nan_log_probs_are_rejected_not_aligned(ka):
+    """A NaN log-prob is an explicit per-lattice error (KA_ERR_NAN -> ValueError), in a single call and inside a
+    batch whose other lattices still come out right.  (The library is built with -fno-honor-nans: a float compare
+    would let the NaN through, the kernels test the bits.)"""
+    rng = np.random.default_rng(5)
+    T, V, S = 900, 39, 200
+    lps = [np.log(rng.dirichlet(np.ones(V), size=T)).astype(np.float32) for _ in range(4)]
+    labs = [rng.integers(1, V, size=S).astype(np.int32) for _ in range(4)]
+    lps[2][T // 2, 7] = np.nan
+    with pytest.raises(ValueError, match="NaN"):
+        ka.ctc_best_path(lps[2], labs[2], verbose=False)
+    res, status, total = ka.ctc_best_path_batch(lps, labs, 1000, 4, return_status=True)
+    assert status == [0, 0, -6, 0]
+    for i in (0, 1, 3):
+        assert _same(res[i], O.ctc_best_path_c(lps[i], labs[i], 1000, 4))
+
+
 @pytest.mark.parametrize("mm", [1, 2, 3, 4])
 def test_random_small_shapes_and_narrow_beams(ka, mm):
     """Many small lattices with odd shapes: T not a multiple of the checkpoint interval, beams narrower than the
