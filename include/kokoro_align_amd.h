@@ -32,6 +32,9 @@ extern "C" {
 #define KA_ERR_HIP (-3)       /* HIP runtime error, text in ka_last_error() */
 #define KA_ERR_NOMEM (-4)
 #define KA_ERR_BAD_LABEL (-5) /* label outside [0,V): reference raises IndexError at align.py:77 */
+#define KA_ERR_NONFINITE (-7) /* tiled form only: an infinity among the log-probs of a lattice whose band is wider than 1009
+                                 positions (narrower ones are handed to the exact kernels; -inf is legal there) */
+#define KA_ERR_INTERNAL (-8)  /* tiled form: a tile's hand-off timed out (an internal error, never an input condition) */
 #define KA_ERR_NAN (-6)       /* a log-prob is NaN: the reference's np.argmax treats NaN as the maximum (align.py:83); that
                                  is not reproduced - the lattice is rejected (fast path, V <= 64, band <= 1009 or tiled form) */
 
@@ -115,6 +118,7 @@ int ka_batch_finish(ka_engine *e, float *total_score, int32_t *status);
 #define KA_MODE_WAVE 1
 #define KA_MODE_WORKGROUP 2
 #define KA_MODE_WAVE_EXACT 3
+#define KA_MODE_TILED 4
 int ka_engine_set_mode(ka_engine *e, int32_t mode);
 
 /* Per-kernel timing of the LAST enqueued batch, measured with HIP events recorded on the

@@ -21,6 +21,7 @@ KA_ERR_HIP = -3
 KA_ERR_NOMEM = -4
 KA_ERR_BAD_LABEL = -5
 KA_ERR_NAN = -6
+KA_ERR_NONFINITE = -7
 KA_MEM_HOST = 0
 KA_MEM_DEVICE = 1
 
@@ -44,7 +45,7 @@ def library_path():
 
 def build_library(force=False):
     """Compile the HIP library for gfx950 (cross-compiles without a GPU)."""
-    srcs = [os.path.join(_PKG, "csrc", f) for f in ("ka_engine.hip", "ka_kernels.hpp")]
+    srcs = [os.path.join(_PKG, "csrc", f) for f in ("ka_engine.hip", "ka_kernels.hpp", "ka_tiled.hpp")]
     srcs.append(os.path.join(os.path.dirname(_PKG), "include", "kokoro_align_amd.h"))
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:
@@ -136,6 +137,8 @@ def check(rc, what):
         raise IndexError(f"{what}: label out of bounds for the vocabulary axis ({msg})")
     if rc == KA_ERR_NAN:
         raise ValueError(f"{what}: log_probs contain NaN ({msg})")
+    if rc == KA_ERR_NONFINITE:
+        raise ValueError(f"{what}: {msg}")
     if rc == KA_ERR_BAD_ARGS:
         raise ValueError(f"{what}: {msg}")
     if rc == KA_ERR_NOMEM:
@@ -166,8 +169,9 @@ class Engine:
 
     def set_mode(self, mode):
         """'auto' | 'wave' (1 wavefront per lattice, checkpointed) | 'workgroup' (4 wavefronts per lattice) |
-        'wave_exact' (1 wavefront per lattice, every back-pointer stored)"""
-        code = {"auto": 0, "wave": 1, "workgroup": 2, "wave_exact": 3}[mode] if isinstance(mode, str) else int(mode)
+        'wave_exact' (1 wavefront per lattice, every back-pointer stored) | 'tiled' (a pipeline of 256-position tiles,
+        one wavefront each: few lattices, any band width)"""
+        code = {"auto": 0, "wave": 1, "workgroup": 2, "wave_exact": 3, "tiled": 4}[mode] if isinstance(mode, str) else int(mode)
         check(self.lib.ka_engine_set_mode(self.handle, code), "ka_engine_set_mode")
 
     def set_profiling(self, on=True):

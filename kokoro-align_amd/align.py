@@ -133,7 +133,7 @@ def ctc_best_path_batch(log_probs_list, labels_list, beam_size=1000, max_move=4,
                                             status.ctypes.data, _lib.KA_MEM_HOST, None)
     results = list(zip(paths, louts, souts))
     if return_status:
-        if rc not in (_lib.KA_OK, _lib.KA_ERR_EMPTY_BEAM, _lib.KA_ERR_BAD_LABEL, _lib.KA_ERR_NAN):
+        if rc not in (_lib.KA_OK, _lib.KA_ERR_EMPTY_BEAM, _lib.KA_ERR_BAD_LABEL, _lib.KA_ERR_NAN, _lib.KA_ERR_NONFINITE):
             _lib.check(rc, "ctc_best_path_batch")
         return results, status.tolist(), total
     _lib.check(rc, "ctc_best_path_batch")
@@ -205,7 +205,7 @@ class DeviceBatch:
         rc = e.lib.ka_batch_finish(e.handle, self.total.ctypes.data, self.status.ctypes.data)
         if raise_on_error:
             _lib.check(rc, "ctc_best_path_batch")
-        elif rc not in (_lib.KA_OK, _lib.KA_ERR_EMPTY_BEAM, _lib.KA_ERR_BAD_LABEL, _lib.KA_ERR_NAN):
+        elif rc not in (_lib.KA_OK, _lib.KA_ERR_EMPTY_BEAM, _lib.KA_ERR_BAD_LABEL, _lib.KA_ERR_NAN, _lib.KA_ERR_NONFINITE):
             _lib.check(rc, "ctc_best_path_batch")
         return self.status
 

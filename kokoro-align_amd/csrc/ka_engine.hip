@@ -6,6 +6,7 @@
 // fails.
 #include "../../include/kokoro_align_amd.h"
 #include "ka_kernels.hpp"
+#include "ka_tiled.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -55,13 +56,64 @@ struct DeviceGuard {
 // KA_MODE_AUTO never picks the 4-wavefront form any more: since the checkpointed forward kernel lost a third of its
 // instructions a lone wavefront does a cfg2 lattice in 11.2 + 8.2 ms against 18.7 + 1.4 ms for four wavefronts with
 // stored back-pointers, and it stays ahead at every batch size (64: 19.9 vs 20.4 ms, 512: 21.4 vs 23.1 ms).
-constexpr int32_t kAutoWorkgroupMaxLattices = 0;
 
 struct Shape {
     int64_t T, S, L, W;
     int32_t labx_len;
     bool fast;
+    // tiled form (ka_tiled.hpp): tiles 0 .. n_act-1 of 256 positions each are alive in frames [t_in, t_end)
+    bool tileable = false;
+    bool tiled = false;          // this call runs the lattice in the tiled form
+    std::vector<int32_t> t_in, t_end;
+    int32_t n_final = 0;         // tiles alive in the last frame
+    uint32_t ck_mask = 1023;     // checkpoint row: position p at float index p & ck_mask
+    size_t ck_pitch = 4096;      // bytes per checkpoint row
+    size_t halo_bytes = 0;       // halo slots of all tile boundaries
 };
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Which frames each 256-position tile is alive in, from the band of align.py:64-65:
+//   lo(t) = max(0, floor(L t / T) - B/2),  hi(t) = min(lo(t) + B, L)
+//   t_in(b)  = first t with hi(t) > 256 b        = 0 if 256 b < B, else ceil((256 b - B + B/2 + 1) T / L)
+//   t_end(b) = first t with lo(t) >= 256 (b+1)   = ceil((256 (b+1) + B/2) T / L), at most T
+void plan_tiles(Shape &sh, int32_t V, int32_t beam, int32_t max_move)
+{
+    sh.tileable = false;
+    if (V > 64 || max_move > 4 || beam < 1 || sh.T >= (int64_t(1) << 26)) return;
+    const int64_t T = sh.T, L = sh.L, B = beam, h = B / 2, P = ka::kTpTile;
+    const int64_t n_tiles = ceil_div(L, P);
+    sh.t_in.clear();
+    sh.t_end.clear();
+    sh.n_final = 0;
+    sh.halo_bytes = 0;
+    for (int64_t b = 0; b < n_tiles; ++b) {
+        const int64_t x = b * P, z = (b + 1) * P;
+        const int64_t ti = x < B ? 0 : ceil_div((x - B + h + 1) * T, L);
+        if (ti >= T) break;
+        const int64_t te = std::min<int64_t>(T, ceil_div((z + h) * T, L));
+        if (te <= ti) return;   // the band jumps over a whole tile in one frame (L/T > 256): not worth a pipeline
+        sh.t_in.push_back((int32_t)ti);
+        sh.t_end.push_back((int32_t)te);
+        if (te == T) ++sh.n_final;
+    }
+    if (sh.t_in.empty()) return;
+    for (size_t b = 0; b + 1 < sh.t_in.size(); ++b)   // boundary above tile b: slots t_in(b) .. t_end(b+1)
+        sh.halo_bytes += align_up((size_t)(sh.t_end[b + 1] - sh.t_in[b] + 1) * 16);
+    // checkpoint row: every tile the band can touch at once spans < W + 512 positions; a power-of-two ring of that
+    // size, or simply the whole label axis when that is not larger
+    size_t ring = 1024;
+    while (ring < (size_t)sh.W + 512) ring *= 2;
+    const size_t whole = (size_t)ceil_div(L, P) * P;
+    if (whole <= ring) {
+        sh.ck_mask = 0xffffffffu;
+        sh.ck_pitch = whole * 4;
+    } else {
+        sh.ck_mask = (uint32_t)ring - 1;
+        sh.ck_pitch = ring * 4;
+    }
+    sh.tileable = true;
+}
 
 bool shape_of(int64_t T, int64_t S, int32_t V, int32_t beam, int32_t max_move, Shape &sh)
 {
@@ -76,16 +128,21 @@ bool shape_of(int64_t T, int64_t S, int32_t V, int32_t beam, int32_t max_move, S
     return true;
 }
 
+// bytes of the back-pointer / checkpoint region of a lattice
+size_t bp_region_bytes(const Shape &sh)
+{
+    size_t b = 0;
+    if (sh.fast) b = (((size_t)sh.T + 3) / 4) * 1024;                       // exact forms: 256 B per frame (checkpoints: 128)
+    else if (!sh.tiled) b = (size_t)sh.T * (size_t)sh.W;                     // generic: a byte per band cell
+    if (sh.tiled) b = std::max(b, (size_t)((sh.T - 1) / ka::kCkFrames) * sh.ck_pitch);
+    return align_up(b);
+}
 // device bytes a lattice needs besides the caller's buffers
 size_t lattice_ws_bytes(const Shape &sh)
 {
-    size_t b = align_up((size_t)sh.labx_len * 4);
-    if (sh.fast) {
-        b += align_up((((size_t)sh.T + 3) / 4) * 1024);
-    } else {
-        b += align_up((size_t)sh.T * (size_t)sh.W);
-        b += align_up((size_t)sh.L * 2 * sizeof(float) + (size_t)sh.L * 2);
-    }
+    size_t b = align_up((size_t)sh.labx_len * 4) + bp_region_bytes(sh);
+    if (!sh.fast && !sh.tiled) b += align_up((size_t)sh.L * 2 * sizeof(float) + (size_t)sh.L * 2);
+    if (sh.tiled) b += sh.halo_bytes;
     return b;
 }
 
@@ -106,6 +163,8 @@ struct ka_engine {
     int32_t *h_meta = nullptr;  // pinned, 4 ints per lattice
     bool pending = false;
     int32_t mode = KA_MODE_AUTO;
+    int32_t n_simd = 1024;                 // SIMDs of the device = persistent workers of the tiled form
+    std::vector<int32_t> wide_tiled;       // last batch: lattices in the tiled form that the exact kernels cannot redo
 };
 
 namespace {
@@ -162,6 +221,14 @@ void launch_forward(const ka::Lattice *d_lats, int n, int32_t *d_meta, hipStream
     hipLaunchKernelGGL((ka::forward_w16_kernel<M, true>), dim3(n), dim3(64), 0, s, d_lats, d_meta, only_flagged);
 }
 
+// exact kernels over lattices another forward kernel has flagged kFlagExact
+template <int M>
+void launch_forward_flagged(const ka::Lattice *d_lats, int n, int32_t *d_meta, hipStream_t s)
+{
+    hipLaunchKernelGGL((ka::forward_w16_kernel<M, false>), dim3(n), dim3(64), 0, s, d_lats, d_meta, 1);
+    hipLaunchKernelGGL((ka::forward_w16_kernel<M, true>), dim3(n), dim3(64), 0, s, d_lats, d_meta, 1);
+}
+
 template <int M>
 void launch_backtrace_rc(const ka::Lattice *d_lats, int n, int32_t *d_meta, hipStream_t s)
 {
@@ -188,6 +255,10 @@ int ka_engine_create(int32_t device, ka_engine **out)
     KA_HIP(guard.enter(device));
     ka_engine *e = new ka_engine();
     e->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->n_simd = 4 * prop.multiProcessorCount;
+    }
     for (int i = 0; i < 5; ++i) {
         hipError_t er = hipEventCreate(&e->ev[i]);
         if (er != hipSuccess) {
@@ -225,18 +296,31 @@ size_t ka_workspace_bytes(int32_t n, const int64_t *T, const int64_t *S, int32_t
 {
     if (n < 0 || !T || !S) return 0;
     size_t total = align_up((size_t)n * sizeof(ka::Lattice)) + align_up((size_t)n * 16);
+    size_t tasks = 0;
+    int64_t ninf_slots = 0;
     for (int32_t i = 0; i < n; ++i) {
         Shape sh;
         if (!shape_of(T[i], S[i], V, beam_size, max_move, sh)) return 0;
-        total += lattice_ws_bytes(sh);
+        size_t plain = lattice_ws_bytes(sh);
+        plan_tiles(sh, V, beam_size, max_move);       // whichever form the call ends up in: the larger of the two
+        if (sh.tileable) {
+            sh.tiled = true;
+            plain = std::max(plain, lattice_ws_bytes(sh));
+            tasks += sh.t_in.size();
+            ninf_slots = std::max<int64_t>(ninf_slots, sh.t_end[0]);
+        }
+        total += plain;
     }
+    if (tasks)
+        total += align_up(align_up((1 + tasks) * 4 + (size_t)n * sizeof(ka::TileAux) + 16, 16)) + align_up(tasks * sizeof(ka::TileTask)) +
+                 align_up((size_t)(ninf_slots + 2 * ka::kTpBlock) * 16);
     return total;
 }
 
 int ka_engine_set_mode(ka_engine *e, int32_t mode)
 {
     if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
-    if (mode != KA_MODE_AUTO && mode != KA_MODE_WAVE && mode != KA_MODE_WORKGROUP && mode != KA_MODE_WAVE_EXACT)
+    if (mode != KA_MODE_AUTO && mode != KA_MODE_WAVE && mode != KA_MODE_WORKGROUP && mode != KA_MODE_WAVE_EXACT && mode != KA_MODE_TILED)
         return fail(KA_ERR_BAD_ARGS, "ka_engine_set_mode: unknown mode");
     e->mode = mode;
     return KA_OK;
@@ -258,6 +342,10 @@ int ka_engine_last_kernel_ms(ka_engine *e, float ms[4])
     return KA_OK;
 }
 
+// The tiled form pays off when the one-wavefront-per-lattice form leaves the chip idle: a lattice costs ~5 concurrently
+// running tile wavefronts (a 1000-wide band touches 4-5 tiles), the chip has 1024 SIMDs.  Measured crossover: DESIGN.md.
+constexpr int32_t kAutoTiledMaxLattices = 160;
+
 static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, const int64_t *T, int32_t V,
                         const int64_t *ld, const int32_t *const *labels, const int64_t *S, int32_t beam_size,
                         int32_t max_move, int32_t *const *best_path, int32_t *const *best_labels,
@@ -273,17 +361,34 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
     e->n_last = n;
     e->stream_last = stream;
     e->have_times = false;
+    e->wide_tiled.clear();
     if (n == 0) {
         e->pending = true;
         return KA_OK;
     }
 
     std::vector<Shape> sh(n);
+    int32_t n_fast_shaped = 0;
     for (int32_t i = 0; i < n; ++i) {
         if (!shape_of(T[i], S[i], V, beam_size, max_move, sh[i]) || ld[i] < V)
             return fail(KA_ERR_BAD_ARGS, "lattice " + std::to_string(i) + ": unsupported T/S/V/ld/beam_size/max_move");
         if (!log_probs[i] || !best_path[i] || !best_labels[i] || !best_scores[i] || (S[i] > 0 && !labels[i]))
             return fail(KA_ERR_BAD_ARGS, "lattice " + std::to_string(i) + ": NULL buffer");
+        n_fast_shaped += sh[i].fast ? 1 : 0;
+    }
+    // ---- which lattices run in the tiled form (ka_tiled.hpp) ----
+    //   KA_MODE_TILED: every lattice that can;  KA_MODE_AUTO: bands too wide for the one-wavefront ring always, the
+    //   others when they are too few to fill the chip with one wavefront each
+    int32_t n_tiled = 0;
+    {
+        const bool all = e->mode == KA_MODE_TILED;
+        const bool few = e->mode == KA_MODE_AUTO && n_fast_shaped <= kAutoTiledMaxLattices;
+        for (int32_t i = 0; i < n; ++i) {
+            if (!(all || (e->mode == KA_MODE_AUTO && (few || !sh[i].fast)))) continue;
+            plan_tiles(sh[i], V, beam_size, max_move);
+            sh[i].tiled = sh[i].tileable;
+            n_tiled += sh[i].tiled ? 1 : 0;
+        }
     }
 
     // ---- carve the workspace ----
@@ -292,15 +397,36 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
     off += align_up((size_t)n * sizeof(ka::Lattice));
     const size_t off_meta = off;
     off += align_up((size_t)n * 16);
-    struct Carve { size_t labx, bp, col, lp, lab, path, labo, sco; };
+    // tiled form, per launch: [progress words | per-lattice terminal records | ticket] (zeroed every launch), the tile
+    // tasks, and the halo region, which starts with the -inf slots that stand in for "the tile below tile 0"
+    size_t n_tasks = 0;
+    int64_t ninf_slots = 0;
+    for (int32_t i = 0; i < n; ++i)
+        if (sh[i].tiled) {
+            n_tasks += sh[i].t_in.size();
+            ninf_slots = std::max<int64_t>(ninf_slots, sh[i].t_end[0]);
+        }
+    const size_t off_zero = off;
+    const size_t zero_bytes = n_tiled ? align_up((1 + n_tasks) * 4 + (size_t)n * sizeof(ka::TileAux) + 16, 16) : 0;
+    const size_t off_prog = off_zero, off_aux = off_zero + align_up((1 + n_tasks) * 4, 16);
+    const size_t off_ticket = off_aux + (size_t)n * sizeof(ka::TileAux);
+    off += align_up(zero_bytes);
+    const size_t off_tasks = off;
+    off += align_up(n_tasks * sizeof(ka::TileTask));
+    const size_t off_halo = off;
+    const size_t ninf_bytes = n_tiled ? align_up((size_t)(ninf_slots + 2 * ka::kTpBlock) * 16) : 0;
+    off += ninf_bytes;
+    struct Carve { size_t labx, bp, col, halo, lp, lab, path, labo, sco; };
     std::vector<Carve> cv(n);
     for (int32_t i = 0; i < n; ++i) {
         cv[i].labx = off;
         off += align_up((size_t)sh[i].labx_len * 4);
         cv[i].bp = off;
-        off += sh[i].fast ? align_up((((size_t)sh[i].T + 3) / 4) * 1024) : align_up((size_t)sh[i].T * (size_t)sh[i].W);
+        off += bp_region_bytes(sh[i]);
         cv[i].col = off;
-        if (!sh[i].fast) off += align_up((size_t)sh[i].L * 2 * sizeof(float) + (size_t)sh[i].L * 2);
+        if (!sh[i].fast && !sh[i].tiled) off += align_up((size_t)sh[i].L * 2 * sizeof(float) + (size_t)sh[i].L * 2);
+        cv[i].halo = off;
+        if (sh[i].tiled) off += sh[i].halo_bytes;
         if (mem == KA_MEM_HOST) {
             cv[i].lp = off;
             off += align_up((size_t)sh[i].T * (size_t)V * 4);
@@ -316,20 +442,22 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
     }
     int rc = ensure_ws(e, off);
     if (rc != KA_OK) return rc;
-    rc = ensure_pin(e, align_up((size_t)n * sizeof(ka::Lattice)) + align_up((size_t)n * 16));
+    rc = ensure_pin(e, align_up((size_t)n * sizeof(ka::Lattice)) + align_up((size_t)n * 16) + align_up(n_tasks * sizeof(ka::TileTask)));
     if (rc != KA_OK) return rc;
 
-    // ---- descriptors: w16 lattices first (longest first: short tail), then generic ones ----
+    // ---- descriptors: tiled lattices first, then the one-wavefront ones (longest first: short tail), then generic ones ----
+    auto klass = [&](int32_t i) { return sh[i].tiled ? 0 : (sh[i].fast ? 1 : 2); };
     std::vector<int32_t> order(n);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-        if (sh[a].fast != sh[b].fast) return sh[a].fast;
+        if (klass(a) != klass(b)) return klass(a) < klass(b);
         return sh[a].T > sh[b].T;
     });
     int32_t n_fast = 0;
-    for (int32_t i = 0; i < n; ++i) n_fast += sh[i].fast ? 1 : 0;
+    for (int32_t i = 0; i < n; ++i) n_fast += klass(i) == 1 ? 1 : 0;
     ka::Lattice *h_lats = reinterpret_cast<ka::Lattice *>(e->pin);
     e->h_meta = reinterpret_cast<int32_t *>(e->pin + align_up((size_t)n * sizeof(ka::Lattice)));
+    ka::TileTask *h_tasks = reinterpret_cast<ka::TileTask *>(e->pin + align_up((size_t)n * sizeof(ka::Lattice)) + align_up((size_t)n * 16));
     for (int32_t k = 0; k < n; ++k) {
         const int32_t i = order[k];
         ka::Lattice &d = h_lats[k];
@@ -361,6 +489,58 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
         d.labx_len = sh[i].labx_len;
         d.W = (int32_t)sh[i].W;
         d.idx = i;
+        d.n_final = sh[i].tiled ? sh[i].n_final : 0;
+        d.ck_mask = sh[i].tiled ? sh[i].ck_mask : 1023u;
+        d.ck_pitch = sh[i].tiled ? (int32_t)sh[i].ck_pitch : 4096;
+        if (sh[i].tiled && !sh[i].fast) e->wide_tiled.push_back(i);
+    }
+    // ---- tile tasks, sorted by first frame (then tile, then lattice): a tile's producer holds an earlier ticket ----
+    if (n_tiled) {
+        struct Key { int32_t t_in, tile, k; };
+        std::vector<Key> keys;
+        keys.reserve(n_tasks);
+        std::vector<size_t> first_word(n, 0);   // progress word of tile 0 of descriptor k (word 0 = "nothing below")
+        size_t w = 1;
+        for (int32_t k = 0; k < n_tiled; ++k) {
+            const Shape &p = sh[order[k]];
+            first_word[k] = w;
+            w += p.t_in.size();
+            for (size_t b = 0; b < p.t_in.size(); ++b) keys.push_back({p.t_in[b], (int32_t)b, k});
+        }
+        std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+            if (a.t_in != b.t_in) return a.t_in < b.t_in;
+            if (a.tile != b.tile) return a.tile < b.tile;
+            return a.k < b.k;
+        });
+        std::vector<std::vector<size_t>> bound(n_tiled);   // halo region offset of the boundary above tile b
+        for (int32_t k = 0; k < n_tiled; ++k) {
+            const int32_t i = order[k];
+            const Shape &p = sh[i];
+            size_t o = cv[i].halo - off_halo;
+            bound[k].resize(p.t_in.size());
+            for (size_t b = 0; b + 1 < p.t_in.size(); ++b) {
+                bound[k][b] = o;
+                o += align_up((size_t)(p.t_end[b + 1] - p.t_in[b] + 1) * 16);
+            }
+        }
+        for (size_t j = 0; j < keys.size(); ++j) {
+            const Key &key = keys[j];
+            const Shape &p = sh[order[key.k]];
+            const size_t b = (size_t)key.tile;
+            ka::TileTask &tk = h_tasks[j];
+            std::memset(&tk, 0, sizeof(tk));
+            tk.lat = key.k;
+            tk.tile = key.tile;
+            tk.t_in = p.t_in[b];
+            tk.t_end = p.t_end[b];
+            // slot j of a boundary lies at its base + (j - t_in(lower tile)) * 16; the reader addresses from ITS t_in
+            tk.halo_in = b == 0 ? 0 : (int64_t)(bound[key.k][b - 1] + (size_t)(p.t_in[b] - p.t_in[b - 1]) * 16);
+            const bool has_above = b + 1 < p.t_in.size();
+            tk.halo_out = has_above ? (int64_t)bound[key.k][b] : -1;
+            tk.fill_end = has_above ? p.t_end[b + 1] - 1 : 0;
+            tk.prog_in = b == 0 ? 0 : (int32_t)(first_word[key.k] + b - 1);
+            tk.prog_out = (int32_t)(first_word[key.k] + b);
+        }
     }
 
     // ---- copy in (host mode) ----
@@ -376,54 +556,87 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
     int32_t *d_meta = reinterpret_cast<int32_t *>(e->ws + off_meta);
     KA_HIP(hipMemcpyAsync(d_lats, h_lats, (size_t)n * sizeof(ka::Lattice), hipMemcpyHostToDevice, stream));
     KA_HIP(hipMemsetAsync(d_meta, 0, (size_t)n * 16, stream));
+    if (n_tiled) {
+        KA_HIP(hipMemcpyAsync(e->ws + off_tasks, h_tasks, n_tasks * sizeof(ka::TileTask), hipMemcpyHostToDevice, stream));
+        KA_HIP(hipMemsetAsync(e->ws + off_zero, 0, zero_bytes, stream));
+        KA_HIP(hipMemsetD32Async((hipDeviceptr_t)(e->ws + off_prog), (int)ka::kTpProgDone, 1, stream));
+        KA_HIP(hipMemsetD32Async((hipDeviceptr_t)(e->ws + off_halo), (int)0xff800000u, ninf_bytes / 4, stream));   // -inf packets
+    }
 
     // ---- kernels ----
+    // descriptors [0, n_tiled) tiled, [n_tiled, n_tiled + n_fast) one wavefront each, the rest generic
+    const int32_t n_ring = n_tiled + n_fast;   // lattices whose checkpointed results backtrace_rc walks / exact kernels may redo
     if (e->profiling) KA_HIP(hipEventRecord(e->ev[0], stream));
     hipLaunchKernelGGL(ka::prep_labels_kernel, dim3(n), dim3(256), 0, stream, d_lats, d_meta);
     if (e->profiling) KA_HIP(hipEventRecord(e->ev[1], stream));
     Form form = kFormWaveExact;
+    if (n_tiled > 0) {
+        const unsigned grid = (unsigned)n_tasks, lds = ka::kTpLdsRequest;
+        const ka::TileTask *d_tasks = reinterpret_cast<const ka::TileTask *>(e->ws + off_tasks);
+        char *d_halo = e->ws + off_halo;
+        uint32_t *d_prog = reinterpret_cast<uint32_t *>(e->ws + off_prog);
+        ka::TileAux *d_aux = reinterpret_cast<ka::TileAux *>(e->ws + off_aux);
+        uint32_t *d_ticket = reinterpret_cast<uint32_t *>(e->ws + off_ticket);
+        switch (max_move) {
+        case 1: hipLaunchKernelGGL((ka::forward_tp_kernel<1>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket); break;
+        case 2: hipLaunchKernelGGL((ka::forward_tp_kernel<2>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket); break;
+        case 3: hipLaunchKernelGGL((ka::forward_tp_kernel<3>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket); break;
+        default: hipLaunchKernelGGL((ka::forward_tp_kernel<4>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket); break;
+        }
+        form = kFormWaveCheckpointed;
+    }
     if (n_fast > 0) {
         // few lattices: 4 wavefronts per lattice (per-frame latency); many: 1 wavefront per lattice (throughput)
-        const bool wg = e->mode == KA_MODE_WORKGROUP || (e->mode == KA_MODE_AUTO && n_fast <= kAutoWorkgroupMaxLattices);
+        const bool wg = e->mode == KA_MODE_WORKGROUP;
         form = wg ? kFormWorkgroup : (e->mode == KA_MODE_WAVE_EXACT ? kFormWaveExact : kFormWaveCheckpointed);
         // backtrace_rc_kernel keeps 34*T in 32 bits (descriptors are sorted longest first)
-        if (form == kFormWaveCheckpointed && sh[order[0]].T >= (int64_t(1) << 26)) form = kFormWaveExact;
+        if (form == kFormWaveCheckpointed && sh[order[n_tiled]].T >= (int64_t(1) << 26)) form = kFormWaveExact;
         switch (max_move) {
-        case 1: launch_forward<1>(d_lats, n_fast, d_meta, stream, form); break;
-        case 2: launch_forward<2>(d_lats, n_fast, d_meta, stream, form); break;
-        case 3: launch_forward<3>(d_lats, n_fast, d_meta, stream, form); break;
-        default: launch_forward<4>(d_lats, n_fast, d_meta, stream, form); break;
+        case 1: launch_forward<1>(d_lats + n_tiled, n_fast, d_meta, stream, form); break;
+        case 2: launch_forward<2>(d_lats + n_tiled, n_fast, d_meta, stream, form); break;
+        case 3: launch_forward<3>(d_lats + n_tiled, n_fast, d_meta, stream, form); break;
+        default: launch_forward<4>(d_lats + n_tiled, n_fast, d_meta, stream, form); break;
         }
     }
-    if (n > n_fast)
-        hipLaunchKernelGGL(ka::forward_generic_kernel, dim3(n - n_fast), dim3(256), 0, stream, d_lats + n_fast, d_meta);
+    if (n_tiled > 0) {
+        // tiled lattices that the scores-only form declined (non-finite log-probs) and that fit the one-wavefront ring
+        // are redone by the exact kernels (kFlagExact; wider ones get kFlagDeclined and no result)
+        switch (max_move) {
+        case 1: launch_forward_flagged<1>(d_lats, n_tiled, d_meta, stream); break;
+        case 2: launch_forward_flagged<2>(d_lats, n_tiled, d_meta, stream); break;
+        case 3: launch_forward_flagged<3>(d_lats, n_tiled, d_meta, stream); break;
+        default: launch_forward_flagged<4>(d_lats, n_tiled, d_meta, stream); break;
+        }
+    }
+    if (n > n_ring)
+        hipLaunchKernelGGL(ka::forward_generic_kernel, dim3(n - n_ring), dim3(256), 0, stream, d_lats + n_ring, d_meta);
     if (e->profiling) KA_HIP(hipEventRecord(e->ev[2], stream));
-    const int only_flagged = form == kFormWaveCheckpointed ? 1 : 0;
-    if (n_fast > 0) {
-        if (form == kFormWaveCheckpointed) {
-            switch (max_move) {
-            case 1: launch_backtrace_rc<1>(d_lats, n_fast, d_meta, stream); break;
-            case 2: launch_backtrace_rc<2>(d_lats, n_fast, d_meta, stream); break;
-            case 3: launch_backtrace_rc<3>(d_lats, n_fast, d_meta, stream); break;
-            default: launch_backtrace_rc<4>(d_lats, n_fast, d_meta, stream); break;
-            }
+    // backtrace: checkpointed results (tiled + checkpointed one-wavefront form) by recomputation, stored back-pointers by
+    // the walk; [rc_lo, rc_hi) = descriptors whose outputs backtrace_rc writes itself
+    const int32_t rc_lo = 0, rc_hi = n_tiled + (form == kFormWaveCheckpointed ? n_fast : 0);
+    if (rc_hi > rc_lo) {
+        switch (max_move) {
+        case 1: launch_backtrace_rc<1>(d_lats + rc_lo, rc_hi - rc_lo, d_meta, stream); break;
+        case 2: launch_backtrace_rc<2>(d_lats + rc_lo, rc_hi - rc_lo, d_meta, stream); break;
+        case 3: launch_backtrace_rc<3>(d_lats + rc_lo, rc_hi - rc_lo, d_meta, stream); break;
+        default: launch_backtrace_rc<4>(d_lats + rc_lo, rc_hi - rc_lo, d_meta, stream); break;
         }
-        hipLaunchKernelGGL(ka::backtrace_w16_kernel, dim3(n_fast), dim3(64), 0, stream, d_lats, d_meta, only_flagged);
+        hipLaunchKernelGGL(ka::backtrace_w16_kernel, dim3(rc_hi - rc_lo), dim3(64), 0, stream, d_lats + rc_lo, d_meta, 1);
     }
-    if (n > n_fast)
-        hipLaunchKernelGGL(ka::backtrace_generic_kernel, dim3(n - n_fast), dim3(64), 0, stream, d_lats + n_fast, d_meta);
+    if (n_ring > rc_hi)
+        hipLaunchKernelGGL(ka::backtrace_w16_kernel, dim3(n_ring - rc_hi), dim3(64), 0, stream, d_lats + rc_hi, d_meta, 0);
+    if (n > n_ring)
+        hipLaunchKernelGGL(ka::backtrace_generic_kernel, dim3(n - n_ring), dim3(64), 0, stream, d_lats + n_ring, d_meta);
     if (e->profiling) KA_HIP(hipEventRecord(e->ev[3], stream));
     {
-        // descriptors are sorted fast-first: [0, n_fast) may already have their outputs (checkpointed form)
         int64_t t_max = 1;
         for (int32_t i = 0; i < n; ++i) t_max = std::max<int64_t>(t_max, sh[i].T);
         const unsigned gx = (unsigned)((t_max + 1023) / 1024);
-        const int32_t n_own = only_flagged ? n_fast : 0;   // lattices whose outputs the backtrace kernel wrote itself
-        for (int32_t y0 = 0; y0 < n_own; y0 += 65535) {
-            const unsigned gy = (unsigned)std::min<int32_t>(65535, n_own - y0);
+        for (int32_t y0 = 0; y0 < rc_hi; y0 += 65535) {     // only what the exact kernels redid
+            const unsigned gy = (unsigned)std::min<int32_t>(65535, rc_hi - y0);
             hipLaunchKernelGGL(ka::gather_outputs_kernel, dim3(1, gy), dim3(256), 0, stream, d_lats + y0, d_meta, 1);
         }
-        for (int32_t y0 = n_own; y0 < n; y0 += 65535) {   // grid.y limit
+        for (int32_t y0 = rc_hi; y0 < n; y0 += 65535) {   // grid.y limit
             const unsigned gy = (unsigned)std::min<int32_t>(65535, n - y0);
             hipLaunchKernelGGL(ka::gather_outputs_kernel, dim3(gx, gy), dim3(256), 0, stream, d_lats + y0, d_meta, 0);
         }
@@ -463,6 +676,12 @@ int ka_batch_finish(ka_engine *e, float *total_score, int32_t *status)
     KA_HIP(guard.enter(e->device));
     KA_HIP(hipStreamSynchronize(e->stream_last));
     if (e->profiling && e->n_last > 0) e->have_times = true;
+    // a lattice in the tiled form whose band is wider than the exact kernels' ring and whose log-probs are not all
+    // finite (flag set by the forward kernel) has no result
+    for (int32_t i : e->wide_tiled) {
+        int32_t *m = e->h_meta + 4 * (size_t)i;
+        if (m[0] == KA_OK && (m[2] & ka::kFlagDeclined)) m[0] = KA_ERR_NONFINITE;
+    }
     int first_bad = KA_OK;
     for (int32_t i = 0; i < e->n_last; ++i) {
         const int32_t *m = e->h_meta + 4 * (size_t)i;
@@ -473,6 +692,7 @@ int ka_batch_finish(ka_engine *e, float *total_score, int32_t *status)
             g_err = "lattice " + std::to_string(i) + (m[0] == KA_ERR_EMPTY_BEAM ? ": no live state in the last frame (empty beam)"
                                                       : m[0] == KA_ERR_BAD_LABEL ? ": label outside [0, V)"
                                                       : m[0] == KA_ERR_NAN       ? ": a log-prob is NaN"
+                                                      : m[0] == KA_ERR_NONFINITE ? ": log-probs with infinities in a band wider than 1009 positions (use KA_MODE_WAVE)"
                                                                                  : ": failed");
         }
     }

@@ -55,9 +55,11 @@ typedef KA_GLOBAL const v4i_t *gci4_t;
 constexpr int kStatusOk = 0;
 constexpr int kStatusEmptyBeam = -1;
 constexpr int kStatusBadLabel = -5;
+constexpr int kStatusInternal = -8;  // a tile of the tiled form was never fed by the tile below it (a bug, not an input)
 constexpr int kStatusNaN = -6;      // a log-prob is NaN (the reference's np.argmax would treat it as a maximum: not reproduced)
 constexpr int kFlagZeroLabel = 1;   // meta flags: a transcript label is 0
 constexpr int kFlagExact = 2;       // meta flags: the checkpointed path declined this lattice (non-finite log-probs)
+constexpr int kFlagDeclined = 4;    // meta flags: declined, and too wide for the exact kernels' ring: no result (KA_ERR_NONFINITE)
 
 constexpr int kSlots = 1024;        // 64 lanes x 16 cells
 constexpr int kFastMaxBand = 1009;  // kSlots - 15: widest band the w16 layout can hold
@@ -81,7 +83,13 @@ struct Lattice {
     int32_t T, S, L, V;
     int32_t beam, max_move;
     int32_t labx_len, W;    // W = min(beam, L)
-    int32_t idx, pad;       // index of this lattice in the caller's batch
+    int32_t idx;            // index of this lattice in the caller's batch
+    int32_t n_final;        // tiled form: number of tiles alive in the last frame
+    // checkpointed forms: the scores after frame 32 (k+1) - 1 are row k of `bp`; position p sits at float index
+    // p & ck_mask of its row (one-wavefront form: the 1024-slot ring, mask 1023, pitch 4096; tiled form: a ring that
+    // holds every tile the band can touch, or the whole label axis)
+    uint32_t ck_mask;
+    int32_t ck_pitch;       // bytes
 };
 
 // meta[4*idx + {0,1,2,3}] = status, end position, flags (bit0: a transcript label is 0), total score bits
@@ -1495,8 +1503,9 @@ __global__ __launch_bounds__(64) void backtrace_rc_kernel(const Lattice *__restr
     const int lane = threadIdx.x;
     const int32_t *mt = meta + 4 * (size_t)d.idx;
     const int flags = __builtin_amdgcn_readfirstlane(mt[2]);
-    if (flags & kFlagExact) return;                          // handled by the exact kernels
+    if (flags & (kFlagExact | kFlagDeclined)) return;        // handled by the exact kernels / not at all
     if (((flags & kFlagZeroLabel) != 0) != ZL) return;       // the other instance's lattice (as in the forward kernels)
+    if (__builtin_amdgcn_readfirstlane(mt[0]) != kStatusOk) return;   // rejected (bad label, NaN, empty beam): no path
     int p = __builtin_amdgcn_readfirstlane(mt[1]);
     if (p < 0) return;  // empty beam: status already set by the forward kernel
     const uint32_t T = (uint32_t)__builtin_amdgcn_readfirstlane(d.T);
@@ -1510,6 +1519,8 @@ __global__ __launch_bounds__(64) void backtrace_rc_kernel(const Lattice *__restr
     const uint32_t col_off = (lane < d.V ? (uint32_t)lane : 0u) * 4u;
     gci32_t labx = (gci32_t)d.labx;
     const char *ck = reinterpret_cast<const char *>(d.bp);
+    const uint32_t ck_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.ck_mask);
+    const size_t ck_pitch = (size_t)(uint32_t)__builtin_amdgcn_readfirstlane(d.ck_pitch);
     gi32_t path = (gi32_t)d.path;
     gi32_t lab_out = (gi32_t)d.lab_out;
     gf32_t sc_out = (gf32_t)d.sc_out;
@@ -1533,8 +1544,8 @@ __global__ __launch_bounds__(64) void backtrace_rc_kernel(const Lattice *__restr
         asm volatile("global_load_dword %0, %1, %2" : "=v"(lab4) : "v"((uint32_t)lane * 4u), "s"(labx + (wlo >> 1)) : "memory");
         f32x2 ckv = {NINF, NINF};                            // scores of (pb, pb+1) after frame t0-1
         if (t0 != 0) {
-            const uint32_t off = (uint32_t)((pb >> 4) & 63) * 64u + (uint32_t)(pb & 15) * 4u;
-            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(ckv) : "v"(off), "s"(ck + ((size_t)(t0 / kCkFrames) - 1) * 4096) : "memory");
+            const uint32_t off = ((uint32_t)pb & ck_mask) * 4u;   // (pb is even: both cells of the lane lie in one row slot pair)
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(ckv) : "v"(off), "s"(ck + ((size_t)(t0 / kCkFrames) - 1) * ck_pitch) : "memory");
         }
         float rows[kCkFrames];                               // (frames past T-1, last chunk only, repeat row T-1: never walked)
         {

@@ -1,0 +1,517 @@
+// ka_tiled.hpp — tile-pipelined forward DP (KA_MODE_TILED): the lattice is cut along the label axis into tiles of
+// 256 positions, ONE WAVEFRONT OWNS A TILE, and the tiles of a lattice run as a software pipeline.
+//
+// Why: the frame axis is a serial chain.  With one wavefront per lattice (forward_ck_kernel) a frame costs that
+// wavefront ~70 instructions, so a lone lattice - or a book's few dozen chapters - runs at ~0.22 us per frame on a chip
+// that is 99 % idle.  Here a lane owns 4 cells instead of 16 (a frame is ~25 instructions) and the band of a frame is
+// spread over the tiles it touches; dependencies only point UP the label axis (cell p reads p, p-1, p-2, p-3 of the
+// previous frame, align.py:70-81), so tile b may run any number of frames behind tile b-1: there is no barrier, tile b-1
+// publishes its top three cells per frame (a 16-byte "halo" packet in HBM) and tile b consumes them 30-70 frames later.
+//   * Tiles are ABSOLUTE: tile b = positions [256 b, 256 b + 256) for the whole run.  It lives from the frame in which the
+//     band's upper edge reaches it (t_in) to the frame in which the lower edge has passed it (t_end); nothing is
+//     re-labelled and nothing wraps, so any band width works - beam_size >= 2L (the whole lattice, BASELINE configs[4]
+//     "tiled DP") is simply every tile alive for all T frames.
+//   * One single-wavefront workgroup per tile; an LDS request of 40 KB keeps them at one per SIMD (tools/ubench/census.hip:
+//     1024 single-wave workgroups land on 1024 SIMDs), the rest of the grid waits in the dispatcher.  Tiles are drawn from a
+//     ticket counter; the host sorts tasks by t_in, so a tile's producer always holds an earlier ticket.
+//   * Hand-off (cdna_hip_programming.md Guideline 16, sc1 payload + drained + sc1 flag; all loads of it sc1): halo packets
+//     are write-through stores of one lane; a tile publishes "slots < n are complete" once per 16-frame block, n being what
+//     its in-order vmcnt wait has already retired - the publish never waits for anything; the consumer polls that word
+//     once per block, two blocks ahead of use.  Every slot is written once and read once: no ring, no back-pressure.
+//   * Log-prob rows and halo packets are staged through LDS in blocks of 16 frames (loaded one block, written to LDS the
+//     next, consumed the one after: >= 16 frames of latency cover), so the frame loop reads only LDS.
+//   * Scores only, like forward_ck: the score ring is stored every 32 frames (position p at slot p & ck_mask of its
+//     checkpoint row) and backtrace_rc_kernel recomputes the back-pointers around the path.
+#pragma once
+#include "ka_kernels.hpp"
+
+namespace ka {
+
+constexpr int kTpCells = 4;                    // cells per lane
+constexpr int kTpTile = 64 * kTpCells;         // positions per tile
+constexpr int kTpBlock = 16;                   // frames per staging block
+constexpr int kTpRing = 3;                     // LDS staging slots (block k reads slot k % 3, block k+1 is being written)
+constexpr int kTpRowBytes = 256;               // LDS pitch of a staged row (64 columns)
+constexpr uint32_t kTpProgDone = 0x7fffffffu;  // progress word of a finished tile / of "no tile below"
+static_assert(kCkFrames == 2 * kTpBlock, "a checkpoint is taken at the end of every second block");
+
+struct TileTask {
+    int32_t lat;        // index into the launch's Lattice array
+    int32_t tile;       // positions [256 tile, 256 tile + 256)
+    int32_t t_in;       // first frame whose band reaches into the tile (hi(t) > 256 tile)
+    int32_t t_end;      // first frame whose band has left it (lo(t) >= 256 (tile + 1)), or T
+    int64_t halo_in;    // halo region byte offset of slot t_in of the boundary BELOW this tile (tile 0: the -inf region)
+    int64_t halo_out;   // byte offset of slot t_in of the boundary ABOVE this tile; -1: there is no tile above
+    int32_t fill_end;   // last slot of the upper boundary that the tile above reads (its t_end - 1)
+    int32_t prog_in;    // progress word of the tile below (word 0 holds kTpProgDone: nothing below tile 0)
+    int32_t prog_out;   // progress word of this tile
+    int32_t pad;
+};
+// per lattice, zeroed before every launch: terminal state by 64-bit atomicMax, arrival counter of the last-frame tiles
+struct TileAux {
+    unsigned long long best;   // (end position + 1) << 32 | score bits; 0 = no live state
+    uint32_t arrived;
+    uint32_t pad;
+};
+
+typedef uint32_t KA_GLOBAL *gu32w_t;
+
+__device__ __forceinline__ float lds_f32(uint32_t addr) { return *(const __attribute__((address_space(3))) float *)(uintptr_t)addr; }
+__device__ __forceinline__ f32x4 lds_f32x4(uint32_t addr) { return *(const __attribute__((address_space(3))) f32x4 *)(uintptr_t)addr; }
+// lane i <- lane i-1; lane 0 keeps `first` (DPP wave_shr:1, invalid source lanes keep the old value)
+__device__ __forceinline__ float wave_shr1(float first, float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, first), __builtin_bit_cast(int, x), 0x138, 0xF, 0xF, false));
+}
+// lanes [a, b) of a 64-bit mask, any a, b (clamped to 0..64)
+__device__ __forceinline__ uint64_t tp_lane_range(int32_t a, int32_t b)
+{
+    a = a < 0 ? 0 : (a > 64 ? 64 : a);
+    b = b < 0 ? 0 : (b > 64 ? 64 : b);
+    if (b <= a) return 0ull;
+    const uint32_t n = (uint32_t)(b - a);
+    return (n >= 64u ? ~0ull : ((1ull << n) - 1ull)) << a;
+}
+struct TpMasks {
+    uint64_t m0, m1, m2, m3;   // m<k>: lanes whose cell k (position base + 4 lane + k) is inside the band
+};
+// band [lo, hi) relative to the tile's first position (may be negative / beyond the tile)
+__device__ __forceinline__ void tp_masks(TpMasks &mk, int32_t lo_rel, int32_t hi_rel)
+{
+    lo_rel = lo_rel < -8 ? -8 : (lo_rel > kTpTile + 8 ? kTpTile + 8 : lo_rel);
+    hi_rel = hi_rel < -8 ? -8 : (hi_rel > kTpTile + 8 ? kTpTile + 8 : hi_rel);
+    // lanes l with lo_rel <= 4 l + k < hi_rel  <=>  l in [ceil((lo_rel - k) / 4), ceil((hi_rel - k) / 4))
+    mk.m0 = tp_lane_range((lo_rel + 3) >> 2, (hi_rel + 3) >> 2);
+    mk.m1 = tp_lane_range((lo_rel + 2) >> 2, (hi_rel + 2) >> 2);
+    mk.m2 = tp_lane_range((lo_rel + 1) >> 2, (hi_rel + 1) >> 2);
+    mk.m3 = tp_lane_range((lo_rel + 0) >> 2, (hi_rel + 0) >> 2);
+}
+// state of a lane: S = {cell 0, cell 2, cell 1, cell 3} = {blank, blank, label, label} - the two blanks and the two labels
+// are register pairs (v_pk_add_f32 of the emissions), and the four registers as they lie ARE the halo packet
+__device__ __forceinline__ void tp_mask_state(f32x4 &S, const TpMasks &mk, float NINF)
+{
+    S[0] = select_by_mask(NINF, S[0], mk.m0);
+    S[2] = select_by_mask(NINF, S[2], mk.m1);
+    S[1] = select_by_mask(NINF, S[1], mk.m2);
+    S[3] = select_by_mask(NINF, S[3], mk.m3);
+}
+
+// sc1 (write-through, agent scope) accesses of the hand-off.  The loads are untracked by hipcc like the row loads:
+// pair with a counted wait.
+__device__ __forceinline__ void tp_halo_store(const void *slot /* uniform */, const f32x4 &pk, uint64_t lane_mask)
+{
+    // one lane stores: EXEC is narrowed to it and put back as it was (never assumed to be "all lanes": the compiler
+    // may have structured the surrounding control flow with lanes parked).  s_nop: a store wider than 64 bits reads its
+    // data registers for two more wait states, and the next frame rewrites them.
+    uint64_t saved;
+    asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %4\n\tglobal_store_dwordx4 %1, %2, %3 sc1\n\ts_mov_b64 exec, %0\n\ts_nop 0"
+                 : "=&s"(saved) : "v"(0u), "v"(pk), "s"(slot), "s"(lane_mask) : "memory", "scc");
+}
+__device__ __forceinline__ void tp_prog_store(gu32w_t word /* uniform */, uint32_t value)
+{
+    uint64_t saved;
+    asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, 1\n\tglobal_store_dword %1, %2, %3 sc1\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved) : "v"(0u), "v"(value), "s"(word) : "memory", "scc");
+}
+__device__ __forceinline__ void tp_prog_load(uint32_t &dst, gu32w_t word /* uniform */)
+{
+    asm volatile("global_load_dword %0, %1, %2 sc1" : "+v"(dst) : "v"(0u), "s"(word) : "memory");
+}
+// progress of the tile below must reach `need` leading slots; polled relaxed with a sleep that grows while far away.
+// Bounded: a tile whose producer has not delivered within ~4 s of wall clock gives up (returns false; the lattice gets
+// KA_ERR_INTERNAL) instead of hanging the GPU - this can only be a bug in the hand-off, never an input.
+__device__ __forceinline__ bool tp_wait_progress(gu32w_t word, uint32_t need, uint32_t have)
+{
+    if (have >= need) return true;
+    const uint64_t t0 = wall_clock64();   // 100 MHz
+    for (;;) {
+        const uint32_t gap = need - have;
+        if (gap > 4096u) __builtin_amdgcn_s_sleep(127);
+        else if (gap > 256u) __builtin_amdgcn_s_sleep(32);
+        else __builtin_amdgcn_s_sleep(4);
+        uint32_t v = 0;
+        tp_prog_load(v, word);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) : : "memory");
+        have = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+        if (have >= need) return true;
+        if (wall_clock64() - t0 > 400000000ull) return false;
+    }
+}
+
+template <int M, bool ZL>
+struct TpTile {
+    // wave-uniform description of the tile and its lattice
+    uint32_t T, L, B, halfB, dq, dr, thr_real;
+    int32_t base, t_in, t_end;
+    const char *lp;
+    size_t ld;
+    uint32_t lane_off;
+    const char *halo_in;    // slot j of the lower boundary at halo_in + (j - t_in) * 16
+    char *halo_out;         // slot j of the upper boundary at halo_out + (j - t_in) * 16, or null
+    char *out_next;         // the slot the next computed frame publishes
+    gu32w_t prog_in, prog_out;
+    char *ck;               // checkpoint k (scores after frame 32 (k + 1) - 1) at ck + k * ck_pitch
+    size_t ck_pitch;
+    uint32_t ck_off;        // per lane: ((base + 4 lane) & ck_mask) * 4
+    // band state of the frame being computed
+    uint32_t q, rem, lo, hi, thr;
+    TpMasks mk;
+    bool edge;              // the band does not cover the whole tile: masks matter
+    // per lane
+    f32x4 S;
+    int la0, la1;           // 4 * label of cells 1 and 3
+    float vz0, vz1;
+    float absum;
+    // LDS
+    uint32_t lds_rows, lds_halo;   // byte addresses of this workgroup's staging rings
+};
+
+// One frame.  Inputs of the frame (emissions E, e0 and the three cells below each lane's first cell, H) were prepared
+// during the previous frame; the LDS reads for frame t+1 are issued here from `nrow*` (byte address of row t+1 in LDS)
+// and `nhalo`, and H of frame t+1 is taken at the end, from this frame's final scores and the packet of slot t+1.
+// (The DPP moves sit at the END of a frame on purpose: the publishing store behind them narrows EXEC to one lane and
+//  widens it again from inline asm, and a DPP needs five wait states after an EXEC write that the compiler cannot see.)
+template <int M, bool ZL, bool GUARDED>
+__device__ __forceinline__ void tp_frame(TpTile<M, ZL> &c, uint32_t t, f32x2 &E, float &e0, float (&H)[3], uint32_t nrow_l0, uint32_t nrow_l1,
+                                         uint32_t nrow_0, uint32_t nhalo, uint32_t row_off, uint32_t halo_off, uint64_t lane63, float NINF)
+{
+    const bool live = !GUARDED || ((int32_t)t >= c.t_in && (int32_t)t < c.t_end);
+    // LDS reads of frame t+1 (consumed one frame later; skipped frames read too: they prime the pipeline)
+    const f32x2 En = {lds_f32(nrow_l0 + row_off), lds_f32(nrow_l1 + row_off)};
+    const float e0n = lds_f32(nrow_0 + row_off);
+    const f32x4 hpn = lds_f32x4(nhalo + halo_off);   // slot t+1 of the lower boundary: {cell 0, 2, 1, 3} of the lane below lane 0
+    if (live) {
+        const float b0 = c.S[0], b1 = c.S[1], l0 = c.S[2], l1 = c.S[3];
+        f32x2 ml, mb;
+        ml[1] = cell_label_max<M, ZL>(l1, b1, l0, b0, c.vz1);
+        mb[1] = cell_blank_max<M>(b1, l0, H[0]);
+        ml[0] = cell_label_max<M, ZL>(l0, b0, H[0], H[1], c.vz0);
+        mb[0] = cell_blank_max<M>(b0, H[0], H[2]);
+        const f32x2 sl = ml + E, sb = mb + f32x2{e0, e0};
+        c.S = f32x4{sb[0], sb[1], sl[0], sl[1]};
+        // band of the next frame (align.py:64-65), advanced Bresenham-style; the masks matter only while an edge of
+        // the band is inside this tile: (i) before a band step what becomes live must hold -inf, (ii) in the first frame
+        // of a new band what left it on the lo side must die (see forward_ck; there is no ring here, so no (iii))
+        c.rem += c.dr;
+        if (__builtin_expect(c.rem >= c.thr, 0)) {
+            asm volatile("" ::: "memory");
+            c.thr = c.thr_real;
+            if (c.edge) tp_mask_state(c.S, c.mk, NINF);
+            if (c.rem >= c.thr_real) {
+                c.q += c.dq;
+                if (c.rem >= c.T) { c.rem -= c.T; ++c.q; }
+                if (t + 1 != c.T) {
+                    const int32_t dlo = (int32_t)c.q - (int32_t)c.halfB;
+                    const uint32_t nlo = (uint32_t)(dlo > 0 ? dlo : 0);
+                    const uint32_t nhi = (c.L - nlo < c.B) ? c.L : nlo + c.B;
+                    if (nlo != c.lo || nhi != c.hi) {
+                        c.lo = nlo;
+                        c.hi = nhi;
+                        const bool was_edge = c.edge;
+                        c.edge = (int32_t)nlo > c.base || (int32_t)nhi < c.base + kTpTile;
+                        if (c.edge || was_edge) tp_masks(c.mk, (int32_t)nlo - c.base, (int32_t)nhi - c.base);
+                        c.thr = 0;   // frame t+1 is the first of a new band: it must come through here again
+                    }
+                }
+            }
+        }
+    }
+    // the three cells below every lane's first cell, for frame t+1 (lane 0: from the packet of the tile below)
+    // (the packet's first dword is not needed; it is kept alive up to here so that its register is not recycled - and
+    //  the LDS read waited for - at the top of the frame)
+    asm volatile("" : : "v"(hpn));
+    H[0] = wave_shr1(hpn[3], c.S[3]);   // position base + 4 lane - 1 (label)
+    H[1] = wave_shr1(hpn[1], c.S[1]);   // - 2 (blank)
+    H[2] = wave_shr1(hpn[2], c.S[2]);   // - 3 (label)
+    // publish the state after frame t = slot t+1 of the upper boundary (lane 63's four cells)
+    if (live && c.halo_out) {
+        tp_halo_store(c.out_next, c.S, lane63);
+        c.out_next += 16;
+    }
+    E = En;
+    e0 = e0n;
+}
+
+template <int M, bool ZL>
+__device__ __forceinline__ void tp_checkpoint(TpTile<M, ZL> &c, uint32_t t_next /* multiple of 32 */)
+{
+    const f32x4 v = {c.S[0], c.S[2], c.S[1], c.S[3]};   // cells 0..3 in position order
+    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(c.ck_off), "v"(v), "s"(c.ck + ((size_t)(t_next / kCkFrames) - 1) * c.ck_pitch) : "memory");
+}
+
+// ---------------------------------------------------------------------------------------
+// one tile, all its frames
+// ---------------------------------------------------------------------------------------
+template <int M, bool ZL>
+__device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk, int32_t *meta, char *halo, gu32w_t prog, TileAux *aux,
+                                            uint32_t lds_rows, uint32_t lds_halo)
+{
+    const int lane = threadIdx.x;
+    const float NINF = ninf();
+    const uint64_t lane63 = 1ull << 63;
+    TpTile<M, ZL> c;
+    c.T = (uint32_t)__builtin_amdgcn_readfirstlane(d.T);
+    c.L = (uint32_t)__builtin_amdgcn_readfirstlane(d.L);
+    c.B = (uint32_t)__builtin_amdgcn_readfirstlane(d.beam);
+    c.halfB = c.B >> 1;
+    c.dq = c.L / c.T;
+    c.dr = c.L % c.T;
+    c.thr_real = c.dq != 0 ? 0u : c.T;
+    c.base = __builtin_amdgcn_readfirstlane(tk.tile) * kTpTile;
+    c.t_in = __builtin_amdgcn_readfirstlane(tk.t_in);
+    c.t_end = __builtin_amdgcn_readfirstlane(tk.t_end);
+    c.lp = reinterpret_cast<const char *>(d.lp);
+    c.ld = (size_t)d.ld * 4;
+    c.lane_off = (lane < d.V ? (uint32_t)lane : 0u) * 4u;
+    c.halo_in = halo + tk.halo_in;
+    c.halo_out = tk.halo_out >= 0 ? halo + tk.halo_out : nullptr;
+    c.prog_in = prog + tk.prog_in;
+    c.prog_out = prog + tk.prog_out;
+    c.ck = reinterpret_cast<char *>(d.bp);
+    c.ck_pitch = (size_t)(uint32_t)d.ck_pitch;
+    c.ck_off = (((uint32_t)c.base + 4u * (uint32_t)lane) & (uint32_t)d.ck_mask) * 4u;
+    c.lds_rows = lds_rows;
+    c.lds_halo = lds_halo;
+    // band of frame t_in (64-bit division once per tile; wave-uniform)
+    {
+        const uint64_t x = (uint64_t)c.L * (uint64_t)(uint32_t)c.t_in;
+        c.q = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x / c.T));
+        c.rem = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x % c.T));
+        const int32_t dlo = (int32_t)c.q - (int32_t)c.halfB;
+        c.lo = (uint32_t)(dlo > 0 ? dlo : 0);
+        c.hi = (c.L - c.lo < c.B) ? c.L : c.lo + c.B;
+        c.edge = (int32_t)c.lo > c.base || (int32_t)c.hi < c.base + kTpTile;
+        tp_masks(c.mk, (int32_t)c.lo - c.base, (int32_t)c.hi - c.base);
+        c.thr = c.thr_real;
+        asm("" : "+s"(c.thr));
+    }
+    // labels of the lane's two label cells (positions base + 4 lane + 1, + 3); labx is zero padded past S
+    {
+        gci32_t labx = (gci32_t)d.labx + ((size_t)c.base >> 1) + 2 * (size_t)lane;
+        c.la0 = labx[0];
+        c.la1 = labx[1];
+        c.vz0 = (ZL && c.la0 == 0) ? NINF : __builtin_inff();
+        c.vz1 = (ZL && c.la1 == 0) ? NINF : __builtin_inff();
+    }
+    // state before frame t_in: nothing of the tile is live, except the virtual start state (align.py:57-58)
+    c.S = f32x4{NINF, NINF, NINF, NINF};
+    if (c.base == 0 && c.t_in == 0 && lane == 0) c.S[0] = 0.0f;
+    c.absum = 0.0f;
+    if (c.halo_out) tp_halo_store(c.halo_out, c.S, lane63);   // slot t_in: the state before the tile's first frame
+    c.out_next = c.halo_out + 16;
+
+    // ---- staging: block k = frames [16 k, 16 k + 16); rows and halo packets of a block are loaded together ----
+    float rows[kTpBlock];
+    f32x4 hreg = {NINF, NINF, NINF, NINF};
+    uint32_t pv = 0;   // polled progress of the tile below
+    const uint32_t last_row = c.T - 1;
+    const uint32_t last_slot = (uint32_t)c.t_end - 1;     // this tile reads slots t_in .. t_end - 1
+    auto issue_block = [&](uint32_t tb) {
+#pragma unroll
+        for (int f = 0; f < kTpBlock; ++f) {
+            const uint32_t tt = tb + f < last_row ? tb + f : last_row;
+            row_reload(rows[f], c.lane_off, c.lp + (size_t)tt * c.ld);
+        }
+        {
+            uint32_t s = tb + (uint32_t)(lane & (kTpBlock - 1));
+            s = s < (uint32_t)c.t_in ? (uint32_t)c.t_in : (s > last_slot ? last_slot : s);
+            const uint32_t off = (s - (uint32_t)c.t_in) * 16u;
+            asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "+v"(hreg) : "v"(off), "s"(c.halo_in) : "memory");
+        }
+        tp_prog_load(pv, c.prog_in);
+    };
+    // Block landed -> LDS.  `younger` = vector-memory operations issued since the block's loads (halo stores, a
+    // checkpoint): the wait may leave exactly that many in flight, and N must never EXCEED the true count (vmcnt is
+    // an in-order counter: with N larger than the number of younger operations the loads themselves may be among the N).
+    auto land_regs = [&](uint32_t slot) {
+        __attribute__((address_space(3))) float *r = (__attribute__((address_space(3))) float *)(uintptr_t)(c.lds_rows + slot * (kTpBlock * kTpRowBytes));
+#pragma unroll
+        for (int f = 0; f < kTpBlock; ++f) {
+            r[f * 64 + lane] = rows[f];
+            c.absum += __builtin_fabsf(rows[f]);
+        }
+        if (lane < kTpBlock) {
+            __attribute__((address_space(3))) f32x4 *h = (__attribute__((address_space(3))) f32x4 *)(uintptr_t)(c.lds_halo + slot * (kTpBlock * 16));
+            h[lane] = hreg;
+        }
+    };
+    auto land_block = [&](uint32_t slot, uint32_t younger) {
+        // one register per release statement (hipcc may otherwise copy an in-flight register ahead of the wait)
+        if (younger >= kTpBlock + 1) {
+#pragma unroll
+            for (int f = 0; f < kTpBlock; ++f) row_wait<kTpBlock + 1>(rows[f]);
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(hreg) : "i"(kTpBlock + 1) : "memory");
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(pv) : "i"(kTpBlock + 1) : "memory");
+        } else if (younger == kTpBlock) {
+#pragma unroll
+            for (int f = 0; f < kTpBlock; ++f) row_wait<kTpBlock>(rows[f]);
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(hreg) : "i"(kTpBlock) : "memory");
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(pv) : "i"(kTpBlock) : "memory");
+        } else if (younger >= 1) {
+#pragma unroll
+            for (int f = 0; f < kTpBlock; ++f) row_wait<1>(rows[f]);
+            asm volatile("s_waitcnt vmcnt(1)" : "+v"(hreg) : : "memory");
+            asm volatile("s_waitcnt vmcnt(1)" : "+v"(pv) : : "memory");
+        } else {
+#pragma unroll
+            for (int f = 0; f < kTpBlock; ++f) row_wait<0>(rows[f]);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(hreg) : : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv) : : "memory");
+        }
+        land_regs(slot);
+    };
+    // slots the tile below must have published before the halo loads of block tb may be issued
+    auto need_for = [&](uint32_t tb) {
+        const uint32_t n = tb + kTpBlock;
+        return n < (uint32_t)c.t_end ? n : (uint32_t)c.t_end;
+    };
+
+    const uint32_t kb0 = (uint32_t)c.t_in / kTpBlock, kb1 = ((uint32_t)c.t_end - 1) / kTpBlock;   // first and last block
+    // prologue: blocks kb0 and kb0+1
+    bool fed = tp_wait_progress(c.prog_in, need_for(kb0 * kTpBlock), 0);
+    issue_block(kb0 * kTpBlock);
+    land_block(kb0 % kTpRing, 0);
+    fed = fed && tp_wait_progress(c.prog_in, need_for((kb0 + 1) * kTpBlock), (uint32_t)__builtin_amdgcn_readfirstlane((int)pv));
+    issue_block((kb0 + 1) * kTpBlock);
+    uint32_t younger = 0;   // vector-memory operations issued since the last issue_block
+
+    // inputs of the first frame
+    f32x2 E;
+    float e0;
+    float H[3];
+    {
+        const uint32_t f0 = (uint32_t)c.t_in - kb0 * kTpBlock;
+        const uint32_t rb = c.lds_rows + (kb0 % kTpRing) * (kTpBlock * kTpRowBytes) + f0 * kTpRowBytes;
+        E = f32x2{lds_f32(rb + (uint32_t)c.la0), lds_f32(rb + (uint32_t)c.la1)};
+        e0 = lds_f32(rb);
+        const f32x4 hp = lds_f32x4(c.lds_halo + (kb0 % kTpRing) * (kTpBlock * 16) + f0 * 16);
+        H[0] = wave_shr1(hp[3], c.S[3]);
+        H[1] = wave_shr1(hp[1], c.S[1]);
+        H[2] = wave_shr1(hp[2], c.S[2]);
+    }
+
+    for (uint32_t kb = kb0; kb <= kb1; ++kb) {
+        const uint32_t tb = kb * kTpBlock;
+        const uint32_t slot = kb % kTpRing, nslot = (kb + 1) % kTpRing;
+        // block start: block kb+1 has landed -> LDS; publish what the wait has retired; poll; issue block kb+2
+        land_block(nslot, younger);
+        // retired: everything issued before the loads of block kb+1, i.e. the halo stores of blocks <= kb-2 = slots <= 16 (kb-1)
+        if (c.halo_out && kb >= kb0 + 2) tp_prog_store(c.prog_out, tb - kTpBlock + 1);
+        if (kb + 2 <= kb1 && fed) fed = tp_wait_progress(c.prog_in, need_for(tb + 2 * kTpBlock), (uint32_t)__builtin_amdgcn_readfirstlane((int)pv));
+        issue_block(tb + 2 * kTpBlock);
+        // (LDS addresses live in vector registers: say so once per block instead of a v_mov per read)
+        uint32_t rcur = c.lds_rows + slot * (kTpBlock * kTpRowBytes), rnxt = c.lds_rows + nslot * (kTpBlock * kTpRowBytes);
+        uint32_t hcur = c.lds_halo + slot * (kTpBlock * 16), hnxt = c.lds_halo + nslot * (kTpBlock * 16);
+        asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                     : "=&v"(rcur), "=&v"(rnxt), "=&v"(hcur), "=&v"(hnxt) : "s"(rcur), "s"(rnxt), "s"(hcur), "s"(hnxt));
+        const uint32_t l0c = rcur + (uint32_t)c.la0, l1c = rcur + (uint32_t)c.la1, l0n = rnxt + (uint32_t)c.la0, l1n = rnxt + (uint32_t)c.la1;
+        const bool partial = (int32_t)tb < c.t_in || (int32_t)(tb + kTpBlock) > c.t_end;
+        if (!partial) {
+#pragma unroll
+            for (int f = 0; f < kTpBlock; ++f) {
+                if (f < kTpBlock - 1)
+                    tp_frame<M, ZL, false>(c, tb + f, E, e0, H, l0c, l1c, rcur, hcur, (f + 1) * kTpRowBytes, (f + 1) * 16, lane63, NINF);
+                else
+                    tp_frame<M, ZL, false>(c, tb + f, E, e0, H, l0n, l1n, rnxt, hnxt, 0, 0, lane63, NINF);
+            }
+            younger = c.halo_out ? kTpBlock : 0;
+            if ((tb & kTpBlock) && tb + kTpBlock < c.T) {
+                tp_checkpoint(c, tb + kTpBlock);
+                ++younger;
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < kTpBlock; ++f) {
+                if (f < kTpBlock - 1)
+                    tp_frame<M, ZL, true>(c, tb + f, E, e0, H, l0c, l1c, rcur, hcur, (f + 1) * kTpRowBytes, (f + 1) * 16, lane63, NINF);
+                else
+                    tp_frame<M, ZL, true>(c, tb + f, E, e0, H, l0n, l1n, rnxt, hnxt, 0, 0, lane63, NINF);
+            }
+            if ((tb & kTpBlock) && (int32_t)(tb + kTpBlock) <= c.t_end && tb + kTpBlock < c.T) tp_checkpoint(c, tb + kTpBlock);
+            younger = 0;   // a partial block issued some unknown number of stores: the next wait drains everything
+        }
+    }
+    // drain the staging loads still in flight (their registers are dead to the compiler after the loop)
+#pragma unroll
+    for (int f = 0; f < kTpBlock; ++f) row_wait<0>(rows[f]);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(hreg), "+v"(pv) : : "memory");
+
+    // ---- hand the rest of the upper boundary over: after t_end the whole tile is below the band = -inf ----
+    if (c.halo_out) {
+        const f32x4 dead = {NINF, NINF, NINF, NINF};
+        for (int64_t s = (int64_t)c.t_end + 1 + lane; s <= (int64_t)tk.fill_end; s += 64)
+            asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" : : "v"((uint32_t)((s - c.t_in) * 16)), "v"(dead), "s"(c.halo_out) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tp_prog_store(c.prog_out, kTpProgDone);
+    }
+
+    int32_t *m = meta_of(meta, d.idx);
+    if (!fed && lane == 0) atomicMin(&m[0], kStatusInternal);
+    // ---- finiteness (as forward_ck: the scores-only form is valid for finite log-probs of sane magnitude) ----
+    const uint32_t abits = __builtin_bit_cast(uint32_t, c.absum) & 0x7fffffffu;
+    if (__builtin_amdgcn_ballot_w64(abits > 0x7f800000u)) {
+        if (lane == 0) atomicMin(&m[0], kStatusNaN);
+    } else if (__builtin_amdgcn_ballot_w64(abits >= __builtin_bit_cast(uint32_t, 1e30f))) {
+        if (lane == 0) atomicOr(&m[2], d.W <= kFastMaxBand ? kFlagExact : kFlagDeclined);
+    }
+    // ---- terminal state: the HIGHEST live position of frame T-1 (align.py:99-101), over the tiles alive then ----
+    if ((uint32_t)c.t_end == c.T) {
+        tp_masks(c.mk, (int32_t)c.lo - c.base, (int32_t)c.hi - c.base);
+        tp_mask_state(c.S, c.mk, NINF);
+        const float cell[4] = {c.S[0], c.S[2], c.S[1], c.S[3]};
+        unsigned long long key = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (cell[k] != NINF) key = ((unsigned long long)(uint32_t)(c.base + 4 * lane + k + 1) << 32) | __builtin_bit_cast(uint32_t, cell[k]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned long long o = __shfl_xor(key, off);
+            key = o > key ? o : key;
+        }
+        if (lane == 0) {
+            TileAux *a = aux + d.idx;
+            if (key) atomicMax(&a->best, key);
+            __threadfence();
+            const uint32_t n = atomicAdd(&a->arrived, 1u) + 1u;
+            if (n == (uint32_t)d.n_final) {
+                __threadfence();
+                const unsigned long long best = atomicMax(&a->best, 0ull);
+                if (best == 0) {
+                    m[1] = -1;
+                    atomicMin(&m[0], kStatusEmptyBeam);
+                } else {
+                    m[1] = (int32_t)(best >> 32) - 1;
+                    m[3] = (int32_t)(uint32_t)best;
+                }
+            }
+        }
+    }
+}
+
+// One workgroup (one wavefront) per tile.  A workgroup asks for 40 KB of LDS although it uses 13: at most four fit on
+// a CU, i.e. one per SIMD (tools/ubench/census.hip), and the rest of the grid waits in the dispatcher for a tile to
+// finish.  The tile a workgroup runs is drawn from a ticket counter, not from its index: tasks are sorted by first frame,
+// so whatever order the dispatcher starts workgroups in, a tile's producer holds an earlier ticket and is running or done
+// - the earliest unfinished ticket can always run to completion.
+constexpr unsigned kTpLdsRequest = 40 * 1024;
+template <int M>
+__global__ __launch_bounds__(64) void forward_tp_kernel(const Lattice *__restrict__ lats, const TileTask *__restrict__ tasks, int n_tasks,
+                                                        int32_t *meta, char *halo, uint32_t *prog, TileAux *aux, uint32_t *ticket)
+{
+    extern __shared__ __attribute__((aligned(16))) char tp_lds[];
+    const uint32_t lds_rows = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&tp_lds[0];
+    const uint32_t lds_halo = lds_rows + kTpRing * kTpBlock * kTpRowBytes;
+    uint32_t tix = 0;
+    if (threadIdx.x == 0) tix = atomicAdd(ticket, 1u);
+    tix = (uint32_t)__builtin_amdgcn_readfirstlane((int)tix);
+    if (tix >= (uint32_t)n_tasks) return;
+    const TileTask &tk = tasks[tix];
+    const Lattice &d = lats[__builtin_amdgcn_readfirstlane(tk.lat)];
+    const int flags = __builtin_amdgcn_readfirstlane(meta_of(meta, d.idx)[2]);
+    if (flags & kFlagZeroLabel)
+        tp_run_tile<M, true>(d, tk, meta, halo, (gu32w_t)prog, aux, lds_rows, lds_halo);
+    else
+        tp_run_tile<M, false>(d, tk, meta, halo, (gu32w_t)prog, aux, lds_rows, lds_halo);
+}
+
+}  // namespace ka

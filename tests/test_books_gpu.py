@@ -17,7 +17,7 @@ from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 
-MODES = ["wave", "workgroup", "wave_exact"]
+MODES = ["wave", "workgroup", "wave_exact", "tiled"]
 _oracle_cache = {}
 
 
@@ -82,7 +82,7 @@ def test_book_one_launch_every_chapter_vs_oracle(books_on_device, name, mode):
         eng.set_mode("auto")
 
 
-@pytest.mark.parametrize("mode", ["auto"])
+@pytest.mark.parametrize("mode", ["auto", "tiled"])
 def test_meian_sharded_over_8_ranks_equals_one_launch(books_on_device, mode):
     """BASELINE configs[3]: the LPT split of sharding.shard_for_rank, every rank's shard as its own launch."""
     from kokoro_align_amd.align import DeviceBatch

@@ -13,10 +13,10 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["wave", "workgroup", "wave_exact"])
+@pytest.fixture(scope="module", params=["wave", "workgroup", "wave_exact", "tiled"])
 def ka(request):
-    """Every test runs with both forms of the forward kernel: one wavefront per lattice (throughput)
-    and four wavefronts per lattice (latency).  Results must be identical."""
+    """Every test runs in every kernel form: one wavefront per lattice checkpointed / exact,
+    four wavefronts per lattice, and the tile pipeline.  Results must be identical."""
     import torch
     assert torch.cuda.is_available()
     import kokoro_align_amd as ka
