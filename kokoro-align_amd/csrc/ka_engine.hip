@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -572,16 +573,29 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
     Form form = kFormWaveExact;
     if (n_tiled > 0) {
         const unsigned grid = (unsigned)n_tasks, lds = ka::kTpLdsRequest;
+        // KA_TP_VERIFY=1 (tests): every halo slot starts as a NaN pattern and a tile that consumes one reports KA_ERR_INTERNAL
+        static const int verify = [] { const char *v = std::getenv("KA_TP_VERIFY"); return v ? std::atoi(v) : 0; }();
+        if (verify & 1) {
+            size_t lo_b = ~size_t(0), hi_b = 0;
+            for (int32_t i = 0; i < n; ++i)
+                if (sh[i].tiled && sh[i].halo_bytes) {
+                    lo_b = std::min(lo_b, cv[i].halo);
+                    hi_b = std::max(hi_b, cv[i].halo + sh[i].halo_bytes);
+                }
+            for (int32_t i = 0; i < n && hi_b > lo_b; ++i)
+                if (sh[i].tiled && sh[i].halo_bytes)
+                    KA_HIP(hipMemsetD32Async((hipDeviceptr_t)(e->ws + cv[i].halo), (int)ka::kTpSentinel, sh[i].halo_bytes / 4, stream));
+        }
         const ka::TileTask *d_tasks = reinterpret_cast<const ka::TileTask *>(e->ws + off_tasks);
         char *d_halo = e->ws + off_halo;
         uint32_t *d_prog = reinterpret_cast<uint32_t *>(e->ws + off_prog);
         ka::TileAux *d_aux = reinterpret_cast<ka::TileAux *>(e->ws + off_aux);
         uint32_t *d_ticket = reinterpret_cast<uint32_t *>(e->ws + off_ticket);
         switch (max_move) {
-        case 1: hipLaunchKernelGGL((ka::forward_tp_kernel<1>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket); break;
-        case 2: hipLaunchKernelGGL((ka::forward_tp_kernel<2>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket); break;
-        case 3: hipLaunchKernelGGL((ka::forward_tp_kernel<3>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket); break;
-        default: hipLaunchKernelGGL((ka::forward_tp_kernel<4>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket); break;
+        case 1: hipLaunchKernelGGL((ka::forward_tp_kernel<1>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket, verify); break;
+        case 2: hipLaunchKernelGGL((ka::forward_tp_kernel<2>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket, verify); break;
+        case 3: hipLaunchKernelGGL((ka::forward_tp_kernel<3>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket, verify); break;
+        default: hipLaunchKernelGGL((ka::forward_tp_kernel<4>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket, verify); break;
         }
         form = kFormWaveCheckpointed;
     }
@@ -691,6 +705,7 @@ int ka_batch_finish(ka_engine *e, float *total_score, int32_t *status)
             first_bad = m[0];
             g_err = "lattice " + std::to_string(i) + (m[0] == KA_ERR_EMPTY_BEAM ? ": no live state in the last frame (empty beam)"
                                                       : m[0] == KA_ERR_BAD_LABEL ? ": label outside [0, V)"
+                                                      : m[0] == KA_ERR_INTERNAL  ? ": internal error in the tile hand-off"
                                                       : m[0] == KA_ERR_NAN       ? ": a log-prob is NaN"
                                                       : m[0] == KA_ERR_NONFINITE ? ": log-probs with infinities in a band wider than 1009 positions (use KA_MODE_WAVE)"
                                                                                  : ": failed");

@@ -32,6 +32,7 @@ constexpr int kTpTile = 64 * kTpCells;         // positions per tile
 constexpr int kTpBlock = 16;                   // frames per staging block
 constexpr int kTpRing = 3;                     // LDS staging slots (block k reads slot k % 3, block k+1 is being written)
 constexpr int kTpRowBytes = 256;               // LDS pitch of a staged row (64 columns)
+constexpr uint32_t kTpSentinel = 0x7fc0deadu;  // verification fill of the halo region (a NaN: no score is ever NaN)
 constexpr uint32_t kTpProgDone = 0x7fffffffu;  // progress word of a finished tile / of "no tile below"
 static_assert(kCkFrames == 2 * kTpBlock, "a checkpoint is taken at the end of every second block");
 
@@ -244,7 +245,7 @@ __device__ __forceinline__ void tp_checkpoint(TpTile<M, ZL> &c, uint32_t t_next 
 // ---------------------------------------------------------------------------------------
 template <int M, bool ZL>
 __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk, int32_t *meta, char *halo, gu32w_t prog, TileAux *aux,
-                                            uint32_t lds_rows, uint32_t lds_halo)
+                                            uint32_t lds_rows, uint32_t lds_halo, int verify)
 {
     const int lane = threadIdx.x;
     const float NINF = ninf();
@@ -306,7 +307,9 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
     uint32_t pv = 0;   // polled progress of the tile below
     const uint32_t last_row = c.T - 1;
     const uint32_t last_slot = (uint32_t)c.t_end - 1;     // this tile reads slots t_in .. t_end - 1
+    uint32_t issued_tb = 0;
     auto issue_block = [&](uint32_t tb) {
+        issued_tb = tb;
 #pragma unroll
         for (int f = 0; f < kTpBlock; ++f) {
             const uint32_t tt = tb + f < last_row ? tb + f : last_row;
@@ -323,7 +326,18 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
     // Block landed -> LDS.  `younger` = vector-memory operations issued since the block's loads (halo stores, a
     // checkpoint): the wait may leave exactly that many in flight, and N must never EXCEED the true count (vmcnt is
     // an in-order counter: with N larger than the number of younger operations the loads themselves may be among the N).
+    uint32_t landing_tb = 0;   // first frame of the block whose loads are in flight (verification only)
+    bool stale = false;
     auto land_regs = [&](uint32_t slot) {
+        if (verify & 1) {
+            // KA_TP_VERIFY=1: the host filled the halo region with a NaN pattern no score can have; a packet this tile
+            // is about to consume that still holds it was read before the tile below had written it
+            const uint32_t sidx = landing_tb + (uint32_t)(lane & (kTpBlock - 1));
+            const bool mine = lane < kTpBlock && (int32_t)sidx >= c.t_in && (int32_t)sidx < c.t_end;
+            const bool bad = mine && (__builtin_bit_cast(uint32_t, hreg[1]) == kTpSentinel || __builtin_bit_cast(uint32_t, hreg[2]) == kTpSentinel ||
+                                      __builtin_bit_cast(uint32_t, hreg[3]) == kTpSentinel);
+            if (__builtin_amdgcn_ballot_w64(bad)) stale = true;
+        }
         __attribute__((address_space(3))) float *r = (__attribute__((address_space(3))) float *)(uintptr_t)(c.lds_rows + slot * (kTpBlock * kTpRowBytes));
 #pragma unroll
         for (int f = 0; f < kTpBlock; ++f) {
@@ -335,29 +349,36 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
             h[lane] = hreg;
         }
     };
+    // ONE land site and ONE issue site in the whole function (the loop below starts two blocks early to prime the
+    // pipeline): with several, hipcc merges the in-flight registers of the different paths with v_mov copies that
+    // read them before their loads have landed (tools/lint_inflight.py).  The first statement
+    // holds the counted wait - the count is a run-time value, so it is a small scalar branch tree around four
+    // s_waitcnt - and, vmcnt being in order, retires every load of the block; the other registers are released by
+    // statements without instructions.
     auto land_block = [&](uint32_t slot, uint32_t younger) {
-        // one register per release statement (hipcc may otherwise copy an in-flight register ahead of the wait)
-        if (younger >= kTpBlock + 1) {
+        landing_tb = issued_tb;
+        asm volatile("s_cmp_ge_u32 %1, %2\n\t"
+                     "s_cbranch_scc1 .Lka_tp_w17_%=\n\t"
+                     "s_cmp_eq_u32 %1, %3\n\t"
+                     "s_cbranch_scc1 .Lka_tp_w16_%=\n\t"
+                     "s_cmp_ge_u32 %1, 1\n\t"
+                     "s_cbranch_scc1 .Lka_tp_w1_%=\n\t"
+                     "s_waitcnt vmcnt(0)\n\t"
+                     "s_branch .Lka_tp_wend_%=\n"
+                     ".Lka_tp_w1_%=:\n\t"
+                     "s_waitcnt vmcnt(1)\n\t"
+                     "s_branch .Lka_tp_wend_%=\n"
+                     ".Lka_tp_w16_%=:\n\t"
+                     "s_waitcnt vmcnt(%3)\n\t"
+                     "s_branch .Lka_tp_wend_%=\n"
+                     ".Lka_tp_w17_%=:\n\t"
+                     "s_waitcnt vmcnt(%2)\n"
+                     ".Lka_tp_wend_%=:"
+                     : "+v"(rows[0]) : "s"(younger), "i"(kTpBlock + 1), "i"(kTpBlock) : "memory", "scc");
 #pragma unroll
-            for (int f = 0; f < kTpBlock; ++f) row_wait<kTpBlock + 1>(rows[f]);
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(hreg) : "i"(kTpBlock + 1) : "memory");
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(pv) : "i"(kTpBlock + 1) : "memory");
-        } else if (younger == kTpBlock) {
-#pragma unroll
-            for (int f = 0; f < kTpBlock; ++f) row_wait<kTpBlock>(rows[f]);
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(hreg) : "i"(kTpBlock) : "memory");
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(pv) : "i"(kTpBlock) : "memory");
-        } else if (younger >= 1) {
-#pragma unroll
-            for (int f = 0; f < kTpBlock; ++f) row_wait<1>(rows[f]);
-            asm volatile("s_waitcnt vmcnt(1)" : "+v"(hreg) : : "memory");
-            asm volatile("s_waitcnt vmcnt(1)" : "+v"(pv) : : "memory");
-        } else {
-#pragma unroll
-            for (int f = 0; f < kTpBlock; ++f) row_wait<0>(rows[f]);
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(hreg) : : "memory");
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv) : : "memory");
-        }
+        for (int f = 1; f < kTpBlock; ++f) asm volatile("" : "+v"(rows[f]) : : "memory");
+        asm volatile("" : "+v"(hreg) : : "memory");
+        asm volatile("" : "+v"(pv) : : "memory");
         land_regs(slot);
     };
     // slots the tile below must have published before the halo loads of block tb may be issued
@@ -366,45 +387,40 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
         return n < (uint32_t)c.t_end ? n : (uint32_t)c.t_end;
     };
 
-    const uint32_t kb0 = (uint32_t)c.t_in / kTpBlock, kb1 = ((uint32_t)c.t_end - 1) / kTpBlock;   // first and last block
-    // prologue: blocks kb0 and kb0+1
-    bool fed = tp_wait_progress(c.prog_in, need_for(kb0 * kTpBlock), 0);
-    issue_block(kb0 * kTpBlock);
-    land_block(kb0 % kTpRing, 0);
-    fed = fed && tp_wait_progress(c.prog_in, need_for((kb0 + 1) * kTpBlock), (uint32_t)__builtin_amdgcn_readfirstlane((int)pv));
-    issue_block((kb0 + 1) * kTpBlock);
+    const int32_t kb0 = c.t_in / kTpBlock, kb1 = (c.t_end - 1) / kTpBlock;   // first and last block
     uint32_t younger = 0;   // vector-memory operations issued since the last issue_block
-
-    // inputs of the first frame
-    f32x2 E;
-    float e0;
-    float H[3];
-    {
-        const uint32_t f0 = (uint32_t)c.t_in - kb0 * kTpBlock;
-        const uint32_t rb = c.lds_rows + (kb0 % kTpRing) * (kTpBlock * kTpRowBytes) + f0 * kTpRowBytes;
-        E = f32x2{lds_f32(rb + (uint32_t)c.la0), lds_f32(rb + (uint32_t)c.la1)};
-        e0 = lds_f32(rb);
-        const f32x4 hp = lds_f32x4(c.lds_halo + (kb0 % kTpRing) * (kTpBlock * 16) + f0 * 16);
-        H[0] = wave_shr1(hp[3], c.S[3]);
-        H[1] = wave_shr1(hp[1], c.S[1]);
-        H[2] = wave_shr1(hp[2], c.S[2]);
-    }
-
-    for (uint32_t kb = kb0; kb <= kb1; ++kb) {
-        const uint32_t tb = kb * kTpBlock;
-        const uint32_t slot = kb % kTpRing, nslot = (kb + 1) % kTpRing;
-        // block start: block kb+1 has landed -> LDS; publish what the wait has retired; poll; issue block kb+2
-        land_block(nslot, younger);
+    bool fed = true;
+    f32x2 E = {0.0f, 0.0f};
+    float e0 = 0.0f;
+    float H[3] = {NINF, NINF, NINF};
+    // iteration kb: block kb+1 lands, block kb+2 is requested, block kb is computed.  Iterations kb0-2 and kb0-1 only
+    // prime the pipeline (nothing to land in the first, nothing to compute in either).
+    for (int32_t kb = kb0 - 2; kb <= kb1; ++kb) {
+        const uint32_t tb = (uint32_t)(kb * kTpBlock);              // (wraps for the priming iterations of block 0: not used there)
+        const uint32_t slot = (uint32_t)(kb + 3) % kTpRing, nslot = (uint32_t)(kb + 4) % kTpRing;
+        // block kb+1 has landed -> LDS; publish what the wait has retired; poll; request block kb+2
+        if (kb >= kb0 - 1) land_block(nslot, (verify & 2) ? 0u : younger);   // (KA_TP_VERIFY=2/3: full drain, to tell a counting error from a hand-off error)
         // retired: everything issued before the loads of block kb+1, i.e. the halo stores of blocks <= kb-2 = slots <= 16 (kb-1)
         if (c.halo_out && kb >= kb0 + 2) tp_prog_store(c.prog_out, tb - kTpBlock + 1);
-        if (kb + 2 <= kb1 && fed) fed = tp_wait_progress(c.prog_in, need_for(tb + 2 * kTpBlock), (uint32_t)__builtin_amdgcn_readfirstlane((int)pv));
-        issue_block(tb + 2 * kTpBlock);
+        if (kb + 2 <= kb1 && fed) fed = tp_wait_progress(c.prog_in, need_for((uint32_t)((kb + 2) * kTpBlock)), (uint32_t)__builtin_amdgcn_readfirstlane((int)pv));
+        issue_block((uint32_t)((kb + 2) * kTpBlock));
+        younger = 0;
+        if (kb < kb0) continue;
         // (LDS addresses live in vector registers: say so once per block instead of a v_mov per read)
         uint32_t rcur = c.lds_rows + slot * (kTpBlock * kTpRowBytes), rnxt = c.lds_rows + nslot * (kTpBlock * kTpRowBytes);
         uint32_t hcur = c.lds_halo + slot * (kTpBlock * 16), hnxt = c.lds_halo + nslot * (kTpBlock * 16);
         asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
                      : "=&v"(rcur), "=&v"(rnxt), "=&v"(hcur), "=&v"(hnxt) : "s"(rcur), "s"(rnxt), "s"(hcur), "s"(hnxt));
         const uint32_t l0c = rcur + (uint32_t)c.la0, l1c = rcur + (uint32_t)c.la1, l0n = rnxt + (uint32_t)c.la0, l1n = rnxt + (uint32_t)c.la1;
+        if (kb == kb0) {   // inputs of the tile's first frame
+            const uint32_t f0 = (uint32_t)c.t_in - tb;
+            E = f32x2{lds_f32(l0c + f0 * kTpRowBytes), lds_f32(l1c + f0 * kTpRowBytes)};
+            e0 = lds_f32(rcur + f0 * kTpRowBytes);
+            const f32x4 hp = lds_f32x4(hcur + f0 * 16);
+            H[0] = wave_shr1(hp[3], c.S[3]);
+            H[1] = wave_shr1(hp[1], c.S[1]);
+            H[2] = wave_shr1(hp[2], c.S[2]);
+        }
         const bool partial = (int32_t)tb < c.t_in || (int32_t)(tb + kTpBlock) > c.t_end;
         if (!partial) {
 #pragma unroll
@@ -428,7 +444,7 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
                     tp_frame<M, ZL, true>(c, tb + f, E, e0, H, l0n, l1n, rnxt, hnxt, 0, 0, lane63, NINF);
             }
             if ((tb & kTpBlock) && (int32_t)(tb + kTpBlock) <= c.t_end && tb + kTpBlock < c.T) tp_checkpoint(c, tb + kTpBlock);
-            younger = 0;   // a partial block issued some unknown number of stores: the next wait drains everything
+            // (a partial block issued an unknown number of stores: younger stays 0 and the next wait drains everything)
         }
     }
     // drain the staging loads still in flight (their registers are dead to the compiler after the loop)
@@ -446,7 +462,7 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
     }
 
     int32_t *m = meta_of(meta, d.idx);
-    if (!fed && lane == 0) atomicMin(&m[0], kStatusInternal);
+    if ((!fed || stale) && lane == 0) atomicMin(&m[0], kStatusInternal);
     // ---- finiteness (as forward_ck: the scores-only form is valid for finite log-probs of sane magnitude) ----
     const uint32_t abits = __builtin_bit_cast(uint32_t, c.absum) & 0x7fffffffu;
     if (__builtin_amdgcn_ballot_w64(abits > 0x7f800000u)) {
@@ -496,7 +512,7 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
 constexpr unsigned kTpLdsRequest = 40 * 1024;
 template <int M>
 __global__ __launch_bounds__(64) void forward_tp_kernel(const Lattice *__restrict__ lats, const TileTask *__restrict__ tasks, int n_tasks,
-                                                        int32_t *meta, char *halo, uint32_t *prog, TileAux *aux, uint32_t *ticket)
+                                                        int32_t *meta, char *halo, uint32_t *prog, TileAux *aux, uint32_t *ticket, int verify)
 {
     extern __shared__ __attribute__((aligned(16))) char tp_lds[];
     const uint32_t lds_rows = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&tp_lds[0];
@@ -509,9 +525,9 @@ __global__ __launch_bounds__(64) void forward_tp_kernel(const Lattice *__restric
     const Lattice &d = lats[__builtin_amdgcn_readfirstlane(tk.lat)];
     const int flags = __builtin_amdgcn_readfirstlane(meta_of(meta, d.idx)[2]);
     if (flags & kFlagZeroLabel)
-        tp_run_tile<M, true>(d, tk, meta, halo, (gu32w_t)prog, aux, lds_rows, lds_halo);
+        tp_run_tile<M, true>(d, tk, meta, halo, (gu32w_t)prog, aux, lds_rows, lds_halo, verify);
     else
-        tp_run_tile<M, false>(d, tk, meta, halo, (gu32w_t)prog, aux, lds_rows, lds_halo);
+        tp_run_tile<M, false>(d, tk, meta, halo, (gu32w_t)prog, aux, lds_rows, lds_halo, verify);
 }
 
 }  // namespace ka
