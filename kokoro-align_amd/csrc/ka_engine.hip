@@ -99,8 +99,8 @@ void plan_tiles(Shape &sh, int32_t V, int32_t beam, int32_t max_move)
         if (te == T) ++sh.n_final;
     }
     if (sh.t_in.empty()) return;
-    for (size_t b = 0; b + 1 < sh.t_in.size(); ++b)   // boundary above tile b: slots t_in(b) .. t_end(b+1)
-        sh.halo_bytes += align_up((size_t)(sh.t_end[b + 1] - sh.t_in[b] + 1) * 16);
+    for (size_t b = 0; b < sh.t_in.size(); ++b)   // boundary above tile b: slots t_in(b) .. t_end(b+1) (top tile: its own t_end; nobody reads it)
+        sh.halo_bytes += align_up((size_t)(sh.t_end[b + 1 < sh.t_in.size() ? b + 1 : b] - sh.t_in[b] + 1) * 16);
     // checkpoint row: every tile the band can touch at once spans < W + 512 positions; a power-of-two ring of that
     // size, or simply the whole label axis when that is not larger
     size_t ring = 1024;
@@ -519,9 +519,9 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
             const Shape &p = sh[i];
             size_t o = cv[i].halo - off_halo;
             bound[k].resize(p.t_in.size());
-            for (size_t b = 0; b + 1 < p.t_in.size(); ++b) {
+            for (size_t b = 0; b < p.t_in.size(); ++b) {
                 bound[k][b] = o;
-                o += align_up((size_t)(p.t_end[b + 1] - p.t_in[b] + 1) * 16);
+                o += align_up((size_t)(p.t_end[b + 1 < p.t_in.size() ? b + 1 : b] - p.t_in[b] + 1) * 16);
             }
         }
         for (size_t j = 0; j < keys.size(); ++j) {
@@ -537,7 +537,7 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
             // slot j of a boundary lies at its base + (j - t_in(lower tile)) * 16; the reader addresses from ITS t_in
             tk.halo_in = b == 0 ? 0 : (int64_t)(bound[key.k][b - 1] + (size_t)(p.t_in[b] - p.t_in[b - 1]) * 16);
             const bool has_above = b + 1 < p.t_in.size();
-            tk.halo_out = has_above ? (int64_t)bound[key.k][b] : -1;
+            tk.halo_out = (int64_t)bound[key.k][b];
             tk.fill_end = has_above ? p.t_end[b + 1] - 1 : 0;
             tk.prog_in = b == 0 ? 0 : (int32_t)(first_word[key.k] + b - 1);
             tk.prog_out = (int32_t)(first_word[key.k] + b);

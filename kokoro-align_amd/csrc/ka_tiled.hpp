@@ -42,7 +42,7 @@ struct TileTask {
     int32_t t_in;       // first frame whose band reaches into the tile (hi(t) > 256 tile)
     int32_t t_end;      // first frame whose band has left it (lo(t) >= 256 (tile + 1)), or T
     int64_t halo_in;    // halo region byte offset of slot t_in of the boundary BELOW this tile (tile 0: the -inf region)
-    int64_t halo_out;   // byte offset of slot t_in of the boundary ABOVE this tile; -1: there is no tile above
+    int64_t halo_out;   // byte offset of slot t_in of the boundary ABOVE this tile (the top tile has one too: nobody reads it)
     int32_t fill_end;   // last slot of the upper boundary that the tile above reads (its t_end - 1)
     int32_t prog_in;    // progress word of the tile below (word 0 holds kTpProgDone: nothing below tile 0)
     int32_t prog_out;   // progress word of this tile
@@ -99,14 +99,15 @@ __device__ __forceinline__ void tp_mask_state(f32x4 &S, const TpMasks &mk, float
 
 // sc1 (write-through, agent scope) accesses of the hand-off.  The loads are untracked by hipcc like the row loads:
 // pair with a counted wait.
-__device__ __forceinline__ void tp_halo_store(const void *slot /* uniform */, const f32x4 &pk, uint64_t lane_mask)
+template <int OFF>
+__device__ __forceinline__ void tp_halo_store(const void *block_base /* uniform */, const f32x4 &pk, uint64_t lane_mask)
 {
     // one lane stores: EXEC is narrowed to it and put back as it was (never assumed to be "all lanes": the compiler
-    // may have structured the surrounding control flow with lanes parked).  s_nop: a store wider than 64 bits reads its
-    // data registers for two more wait states, and the next frame rewrites them.
+    // may have structured the surrounding control flow with lanes parked).  A store wider than 64 bits reads its data
+    // registers for two more wait states: the EXEC restore and the s_nop are those.
     uint64_t saved;
-    asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %4\n\tglobal_store_dwordx4 %1, %2, %3 sc1\n\ts_mov_b64 exec, %0\n\ts_nop 0"
-                 : "=&s"(saved) : "v"(0u), "v"(pk), "s"(slot), "s"(lane_mask) : "memory", "scc");
+    asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %4\n\tglobal_store_dwordx4 %1, %2, %3 offset:%5 sc1\n\ts_mov_b64 exec, %0\n\ts_nop 0"
+                 : "=&s"(saved) : "v"(0u), "v"(pk), "s"(block_base), "s"(lane_mask), "i"(OFF) : "memory", "scc");
 }
 __device__ __forceinline__ void tp_prog_store(gu32w_t word /* uniform */, uint32_t value)
 {
@@ -148,8 +149,8 @@ struct TpTile {
     size_t ld;
     uint32_t lane_off;
     const char *halo_in;    // slot j of the lower boundary at halo_in + (j - t_in) * 16
-    char *halo_out;         // slot j of the upper boundary at halo_out + (j - t_in) * 16, or null
-    char *out_next;         // the slot the next computed frame publishes
+    char *halo_out;         // slot j of the upper boundary at halo_out + (j - t_in) * 16 (the top tile writes to a boundary nobody reads)
+    const char *out_block;  // slot 16 kb of the block being computed (frame 16 kb + f publishes slot f + 1 of it)
     gu32w_t prog_in, prog_out;
     char *ck;               // checkpoint k (scores after frame 32 (k + 1) - 1) at ck + k * ck_pitch
     size_t ck_pitch;
@@ -167,20 +168,26 @@ struct TpTile {
     uint32_t lds_rows, lds_halo;   // byte addresses of this workgroup's staging rings
 };
 
-// One frame.  Inputs of the frame (emissions E, e0 and the three cells below each lane's first cell, H) were prepared
-// during the previous frame; the LDS reads for frame t+1 are issued here from `nrow*` (byte address of row t+1 in LDS)
-// and `nhalo`, and H of frame t+1 is taken at the end, from this frame's final scores and the packet of slot t+1.
-// (The DPP moves sit at the END of a frame on purpose: the publishing store behind them narrows EXEC to one lane and
-//  widens it again from inline asm, and a DPP needs five wait states after an EXEC write that the compiler cannot see.)
-template <int M, bool ZL, bool GUARDED>
-__device__ __forceinline__ void tp_frame(TpTile<M, ZL> &c, uint32_t t, f32x2 &E, float &e0, float (&H)[3], uint32_t nrow_l0, uint32_t nrow_l1,
-                                         uint32_t nrow_0, uint32_t nhalo, uint32_t row_off, uint32_t halo_off, uint64_t lane63, float NINF)
+// One frame, F = its index in the block.  The LDS reads run TWO frames ahead of their use (an LDS read takes longer than
+// half a frame of this loop): In.cur = inputs of this frame (emissions E, e0 and H, the three cells below each lane's
+// first cell), In.nxt = raw LDS data of frame t+1 (issued a frame ago, landed by now), and the reads for frame t+2 are
+// issued here from `r2_*` / `h2` (byte addresses of row / packet t+2 in LDS).  H of frame t+1 is taken at the end, from
+// this frame's final scores and the packet of slot t+1.
+struct TpIn {
+    f32x2 E;      // emissions of the two label cells
+    float e0;     // blank emission
+    f32x4 hp;     // packet of the tile below: {cell 0, 2, 1, 3} of the lane below lane 0
+};
+template <int M, bool ZL, bool GUARDED, int F>
+__device__ __forceinline__ void tp_frame(TpTile<M, ZL> &c, uint32_t t, float (&H)[3], TpIn &cur, TpIn &nxt, uint32_t r2_l0, uint32_t r2_l1, uint32_t r2_0,
+                                         uint32_t h2, uint64_t lane63, float NINF)
 {
     const bool live = !GUARDED || ((int32_t)t >= c.t_in && (int32_t)t < c.t_end);
-    // LDS reads of frame t+1 (consumed one frame later; skipped frames read too: they prime the pipeline)
-    const f32x2 En = {lds_f32(nrow_l0 + row_off), lds_f32(nrow_l1 + row_off)};
-    const float e0n = lds_f32(nrow_0 + row_off);
-    const f32x4 hpn = lds_f32x4(nhalo + halo_off);   // slot t+1 of the lower boundary: {cell 0, 2, 1, 3} of the lane below lane 0
+    // LDS reads of frame t+2 (skipped frames read too: they prime the pipeline)
+    TpIn far;
+    far.E = f32x2{lds_f32(r2_l0), lds_f32(r2_l1)};
+    far.e0 = lds_f32(r2_0);
+    far.hp = lds_f32x4(h2);
     if (live) {
         const float b0 = c.S[0], b1 = c.S[1], l0 = c.S[2], l1 = c.S[3];
         f32x2 ml, mb;
@@ -188,7 +195,7 @@ __device__ __forceinline__ void tp_frame(TpTile<M, ZL> &c, uint32_t t, f32x2 &E,
         mb[1] = cell_blank_max<M>(b1, l0, H[0]);
         ml[0] = cell_label_max<M, ZL>(l0, b0, H[0], H[1], c.vz0);
         mb[0] = cell_blank_max<M>(b0, H[0], H[2]);
-        const f32x2 sl = ml + E, sb = mb + f32x2{e0, e0};
+        const f32x2 sl = ml + cur.E, sb = mb + f32x2{cur.e0, cur.e0};
         c.S = f32x4{sb[0], sb[1], sl[0], sl[1]};
         // band of the next frame (align.py:64-65), advanced Bresenham-style; the masks matter only while an edge of
         // the band is inside this tile: (i) before a band step what becomes live must hold -inf, (ii) in the first frame
@@ -219,18 +226,30 @@ __device__ __forceinline__ void tp_frame(TpTile<M, ZL> &c, uint32_t t, f32x2 &E,
     }
     // the three cells below every lane's first cell, for frame t+1 (lane 0: from the packet of the tile below)
     // (the packet's first dword is not needed; it is kept alive up to here so that its register is not recycled - and
-    //  the LDS read waited for - at the top of the frame)
-    asm volatile("" : : "v"(hpn));
-    H[0] = wave_shr1(hpn[3], c.S[3]);   // position base + 4 lane - 1 (label)
-    H[1] = wave_shr1(hpn[1], c.S[1]);   // - 2 (blank)
-    H[2] = wave_shr1(hpn[2], c.S[2]);   // - 3 (label)
+    //  the LDS read waited for - earlier)
+    asm volatile("" : : "v"(nxt.hp));
+    H[0] = wave_shr1(nxt.hp[3], c.S[3]);   // position base + 4 lane - 1 (label)
+    H[1] = wave_shr1(nxt.hp[1], c.S[1]);   // - 2 (blank)
+    H[2] = wave_shr1(nxt.hp[2], c.S[2]);   // - 3 (label)
     // publish the state after frame t = slot t+1 of the upper boundary (lane 63's four cells)
-    if (live && c.halo_out) {
-        tp_halo_store(c.out_next, c.S, lane63);
-        c.out_next += 16;
-    }
-    E = En;
-    e0 = e0n;
+    if (live) tp_halo_store<(F + 1) * 16>(c.out_block, c.S, lane63);
+    cur = nxt;
+    nxt = far;
+}
+
+// the 16 frames of a block.  LDS byte addresses of this block's slot (A[0]) and the next one's (A[1]): row 0 + the lane's
+// two label columns, row 0 itself (column 0 = blank), packet 0 - per block, so that a frame adds only an immediate offset
+struct TpAddr {
+    uint32_t l0, l1, r, h;
+};
+template <int M, bool ZL, bool GUARDED, int F>
+__device__ __forceinline__ void tp_block_frames(TpTile<M, ZL> &c, uint32_t tb, float (&H)[3], TpIn &cur, TpIn &nxt, const TpAddr (&A)[2], uint64_t lane63, float NINF)
+{
+    // frame t+2 = F+2 of this block, or F+2-16 of the next one
+    constexpr int F2 = (F + 2) % kTpBlock, W = (F + 2) / kTpBlock;
+    tp_frame<M, ZL, GUARDED, F>(c, tb + F, H, cur, nxt, A[W].l0 + F2 * kTpRowBytes, A[W].l1 + F2 * kTpRowBytes, A[W].r + F2 * kTpRowBytes, A[W].h + F2 * 16,
+                                lane63, NINF);
+    if constexpr (F + 1 < kTpBlock) tp_block_frames<M, ZL, GUARDED, F + 1>(c, tb, H, cur, nxt, A, lane63, NINF);
 }
 
 template <int M, bool ZL>
@@ -265,7 +284,7 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
     c.ld = (size_t)d.ld * 4;
     c.lane_off = (lane < d.V ? (uint32_t)lane : 0u) * 4u;
     c.halo_in = halo + tk.halo_in;
-    c.halo_out = tk.halo_out >= 0 ? halo + tk.halo_out : nullptr;
+    c.halo_out = halo + tk.halo_out;
     c.prog_in = prog + tk.prog_in;
     c.prog_out = prog + tk.prog_out;
     c.ck = reinterpret_cast<char *>(d.bp);
@@ -298,8 +317,7 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
     c.S = f32x4{NINF, NINF, NINF, NINF};
     if (c.base == 0 && c.t_in == 0 && lane == 0) c.S[0] = 0.0f;
     c.absum = 0.0f;
-    if (c.halo_out) tp_halo_store(c.halo_out, c.S, lane63);   // slot t_in: the state before the tile's first frame
-    c.out_next = c.halo_out + 16;
+    tp_halo_store<0>(c.halo_out, c.S, lane63);   // slot t_in: the state before the tile's first frame
 
     // ---- staging: block k = frames [16 k, 16 k + 16); rows and halo packets of a block are loaded together ----
     float rows[kTpBlock];
@@ -390,8 +408,7 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
     const int32_t kb0 = c.t_in / kTpBlock, kb1 = (c.t_end - 1) / kTpBlock;   // first and last block
     uint32_t younger = 0;   // vector-memory operations issued since the last issue_block
     bool fed = true;
-    f32x2 E = {0.0f, 0.0f};
-    float e0 = 0.0f;
+    TpIn cur = {f32x2{0.0f, 0.0f}, 0.0f, f32x4{NINF, NINF, NINF, NINF}}, nxt = cur;
     float H[3] = {NINF, NINF, NINF};
     // iteration kb: block kb+1 lands, block kb+2 is requested, block kb is computed.  Iterations kb0-2 and kb0-1 only
     // prime the pipeline (nothing to land in the first, nothing to compute in either).
@@ -401,74 +418,68 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
         // block kb+1 has landed -> LDS; publish what the wait has retired; poll; request block kb+2
         if (kb >= kb0 - 1) land_block(nslot, (verify & 2) ? 0u : younger);   // (KA_TP_VERIFY=2/3: full drain, to tell a counting error from a hand-off error)
         // retired: everything issued before the loads of block kb+1, i.e. the halo stores of blocks <= kb-2 = slots <= 16 (kb-1)
-        if (c.halo_out && kb >= kb0 + 2) tp_prog_store(c.prog_out, tb - kTpBlock + 1);
+        if (kb >= kb0 + 2) tp_prog_store(c.prog_out, tb - kTpBlock + 1);
         if (kb + 2 <= kb1 && fed) fed = tp_wait_progress(c.prog_in, need_for((uint32_t)((kb + 2) * kTpBlock)), (uint32_t)__builtin_amdgcn_readfirstlane((int)pv));
         issue_block((uint32_t)((kb + 2) * kTpBlock));
         younger = 0;
         if (kb < kb0) continue;
         // (LDS addresses live in vector registers: say so once per block instead of a v_mov per read)
-        uint32_t rcur = c.lds_rows + slot * (kTpBlock * kTpRowBytes), rnxt = c.lds_rows + nslot * (kTpBlock * kTpRowBytes);
-        uint32_t hcur = c.lds_halo + slot * (kTpBlock * 16), hnxt = c.lds_halo + nslot * (kTpBlock * 16);
+        uint32_t rc = c.lds_rows + slot * (kTpBlock * kTpRowBytes), rn = c.lds_rows + nslot * (kTpBlock * kTpRowBytes);
+        uint32_t hc = c.lds_halo + slot * (kTpBlock * 16), hn = c.lds_halo + nslot * (kTpBlock * 16);
         asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
-                     : "=&v"(rcur), "=&v"(rnxt), "=&v"(hcur), "=&v"(hnxt) : "s"(rcur), "s"(rnxt), "s"(hcur), "s"(hnxt));
-        const uint32_t l0c = rcur + (uint32_t)c.la0, l1c = rcur + (uint32_t)c.la1, l0n = rnxt + (uint32_t)c.la0, l1n = rnxt + (uint32_t)c.la1;
-        if (kb == kb0) {   // inputs of the tile's first frame
-            const uint32_t f0 = (uint32_t)c.t_in - tb;
-            E = f32x2{lds_f32(l0c + f0 * kTpRowBytes), lds_f32(l1c + f0 * kTpRowBytes)};
-            e0 = lds_f32(rcur + f0 * kTpRowBytes);
-            const f32x4 hp = lds_f32x4(hcur + f0 * 16);
+                     : "=&v"(rc), "=&v"(rn), "=&v"(hc), "=&v"(hn) : "s"(rc), "s"(rn), "s"(hc), "s"(hn));
+        TpAddr A[2] = {{rc + (uint32_t)c.la0, rc + (uint32_t)c.la1, rc, hc}, {rn + (uint32_t)c.la0, rn + (uint32_t)c.la1, rn, hn}};
+        asm volatile("" : "+v"(A[0].l0), "+v"(A[0].l1), "+v"(A[1].l0), "+v"(A[1].l1));   // (keep the four sums: no re-add per frame)
+        c.out_block = c.halo_out + ((int64_t)tb - (int64_t)c.t_in) * 16;
+        if (kb == kb0) {
+            // prime the two-frame read pipeline at the block's frames 0 and 1; when the tile starts later in the block,
+            // the skipped frames in front of it shift the pipeline along (and take H afresh) exactly like computed ones
+            cur.E = f32x2{lds_f32(A[0].l0), lds_f32(A[0].l1)};
+            cur.e0 = lds_f32(A[0].r);
+            nxt.E = f32x2{lds_f32(A[0].l0 + kTpRowBytes), lds_f32(A[0].l1 + kTpRowBytes)};
+            nxt.e0 = lds_f32(A[0].r + kTpRowBytes);
+            nxt.hp = lds_f32x4(A[0].h + 16);
+            const f32x4 hp = lds_f32x4(A[0].h);
             H[0] = wave_shr1(hp[3], c.S[3]);
             H[1] = wave_shr1(hp[1], c.S[1]);
             H[2] = wave_shr1(hp[2], c.S[2]);
         }
         const bool partial = (int32_t)tb < c.t_in || (int32_t)(tb + kTpBlock) > c.t_end;
         if (!partial) {
-#pragma unroll
-            for (int f = 0; f < kTpBlock; ++f) {
-                if (f < kTpBlock - 1)
-                    tp_frame<M, ZL, false>(c, tb + f, E, e0, H, l0c, l1c, rcur, hcur, (f + 1) * kTpRowBytes, (f + 1) * 16, lane63, NINF);
-                else
-                    tp_frame<M, ZL, false>(c, tb + f, E, e0, H, l0n, l1n, rnxt, hnxt, 0, 0, lane63, NINF);
-            }
-            younger = c.halo_out ? kTpBlock : 0;
+            tp_block_frames<M, ZL, false, 0>(c, tb, H, cur, nxt, A, lane63, NINF);
+            younger = kTpBlock;
             if ((tb & kTpBlock) && tb + kTpBlock < c.T) {
                 tp_checkpoint(c, tb + kTpBlock);
                 ++younger;
             }
         } else {
-#pragma unroll
-            for (int f = 0; f < kTpBlock; ++f) {
-                if (f < kTpBlock - 1)
-                    tp_frame<M, ZL, true>(c, tb + f, E, e0, H, l0c, l1c, rcur, hcur, (f + 1) * kTpRowBytes, (f + 1) * 16, lane63, NINF);
-                else
-                    tp_frame<M, ZL, true>(c, tb + f, E, e0, H, l0n, l1n, rnxt, hnxt, 0, 0, lane63, NINF);
-            }
+            tp_block_frames<M, ZL, true, 0>(c, tb, H, cur, nxt, A, lane63, NINF);
             if ((tb & kTpBlock) && (int32_t)(tb + kTpBlock) <= c.t_end && tb + kTpBlock < c.T) tp_checkpoint(c, tb + kTpBlock);
             // (a partial block issued an unknown number of stores: younger stays 0 and the next wait drains everything)
         }
     }
-    // drain the staging loads still in flight (their registers are dead to the compiler after the loop)
-#pragma unroll
-    for (int f = 0; f < kTpBlock; ++f) row_wait<0>(rows[f]);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(hreg), "+v"(pv) : : "memory");
+    // drain the staging loads still in flight (their registers are dead to the compiler after the loop and would be
+    // reused while a load can still land in them).  No register operands here: nothing reads those registers again,
+    // and tying them in makes hipcc merge the loop-exit paths with copies of in-flight registers.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // ---- hand the rest of the upper boundary over: after t_end the whole tile is below the band = -inf ----
-    if (c.halo_out) {
-        const f32x4 dead = {NINF, NINF, NINF, NINF};
-        for (int64_t s = (int64_t)c.t_end + 1 + lane; s <= (int64_t)tk.fill_end; s += 64)
-            asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" : : "v"((uint32_t)((s - c.t_in) * 16)), "v"(dead), "s"(c.halo_out) : "memory");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        tp_prog_store(c.prog_out, kTpProgDone);
-    }
-
+    // ---- finiteness (as forward_ck: the scores-only form is valid for finite log-probs of sane magnitude).  Flagged
+    // before the tile reports itself done, so that whoever closes the lattice sees the flag.
     int32_t *m = meta_of(meta, d.idx);
     if ((!fed || stale) && lane == 0) atomicMin(&m[0], kStatusInternal);
-    // ---- finiteness (as forward_ck: the scores-only form is valid for finite log-probs of sane magnitude) ----
     const uint32_t abits = __builtin_bit_cast(uint32_t, c.absum) & 0x7fffffffu;
     if (__builtin_amdgcn_ballot_w64(abits > 0x7f800000u)) {
         if (lane == 0) atomicMin(&m[0], kStatusNaN);
     } else if (__builtin_amdgcn_ballot_w64(abits >= __builtin_bit_cast(uint32_t, 1e30f))) {
         if (lane == 0) atomicOr(&m[2], d.W <= kFastMaxBand ? kFlagExact : kFlagDeclined);
+    }
+    // ---- hand the rest of the upper boundary over: after t_end the whole tile is below the band = -inf ----
+    {
+        const f32x4 dead = {NINF, NINF, NINF, NINF};
+        for (int64_t s = (int64_t)c.t_end + 1 + lane; s <= (int64_t)tk.fill_end; s += 64)
+            asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" : : "v"((uint32_t)((s - c.t_in) * 16)), "v"(dead), "s"(c.halo_out) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tp_prog_store(c.prog_out, kTpProgDone);
     }
     // ---- terminal state: the HIGHEST live position of frame T-1 (align.py:99-101), over the tiles alive then ----
     if ((uint32_t)c.t_end == c.T) {
@@ -492,7 +503,10 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
             if (n == (uint32_t)d.n_final) {
                 __threadfence();
                 const unsigned long long best = atomicMax(&a->best, 0ull);
-                if (best == 0) {
+                const int fl = atomicOr(&m[2], 0);
+                if (fl & (kFlagExact | kFlagDeclined)) {
+                    m[1] = -1;   // declined: the exact kernels redo the lattice (or nobody does: KA_ERR_NONFINITE)
+                } else if (best == 0) {
                     m[1] = -1;
                     atomicMin(&m[0], kStatusEmptyBeam);
                 } else {
