@@ -87,6 +87,17 @@ __device__ __forceinline__ void tp_masks(TpMasks &mk, int32_t lo_rel, int32_t hi
     mk.m2 = tp_lane_range((lo_rel + 1) >> 2, (hi_rel + 1) >> 2);
     mk.m3 = tp_lane_range((lo_rel + 0) >> 2, (hi_rel + 0) >> 2);
 }
+// the position `rel` (relative to the tile's first one; anywhere) enters or leaves the band: flip its lane bit
+__device__ __forceinline__ void tp_mask_toggle(TpMasks &mk, int32_t rel)
+{
+    if (rel < 0 || rel >= kTpTile) return;
+    const uint64_t bit = 1ull << ((uint32_t)rel >> 2);
+    const uint32_t k = (uint32_t)rel & 3u;
+    mk.m0 ^= k == 0 ? bit : 0ull;
+    mk.m1 ^= k == 1 ? bit : 0ull;
+    mk.m2 ^= k == 2 ? bit : 0ull;
+    mk.m3 ^= k == 3 ? bit : 0ull;
+}
 // state of a lane: S = {cell 0, cell 2, cell 1, cell 3} = {blank, blank, label, label} - the two blanks and the two labels
 // are register pairs (v_pk_add_f32 of the emissions), and the four registers as they lie ARE the halo packet
 __device__ __forceinline__ void tp_mask_state(f32x4 &S, const TpMasks &mk, float NINF)
@@ -106,8 +117,15 @@ __device__ __forceinline__ void tp_halo_store(const void *block_base /* uniform 
     // may have structured the surrounding control flow with lanes parked).  A store wider than 64 bits reads its data
     // registers for two more wait states: the EXEC restore and the s_nop are those.
     uint64_t saved;
+#if defined(KA_TP_EXP) && KA_TP_EXP == 1   // timing experiment only (results wrong across XCDs): plain stores
+    asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %4\n\tglobal_store_dwordx4 %1, %2, %3 offset:%5\n\ts_mov_b64 exec, %0\n\ts_nop 0"
+                 : "=&s"(saved) : "v"(0u), "v"(pk), "s"(block_base), "s"(lane_mask), "i"(OFF) : "memory", "scc");
+#elif defined(KA_TP_EXP) && KA_TP_EXP == 2   // timing experiment only: no halo stores at all
+    (void)saved;
+#else
     asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %4\n\tglobal_store_dwordx4 %1, %2, %3 offset:%5 sc1\n\ts_mov_b64 exec, %0\n\ts_nop 0"
                  : "=&s"(saved) : "v"(0u), "v"(pk), "s"(block_base), "s"(lane_mask), "i"(OFF) : "memory", "scc");
+#endif
 }
 __device__ __forceinline__ void tp_prog_store(gu32w_t word /* uniform */, uint32_t value)
 {
@@ -122,12 +140,15 @@ __device__ __forceinline__ void tp_prog_load(uint32_t &dst, gu32w_t word /* unif
 // progress of the tile below must reach `need` leading slots; polled relaxed with a sleep that grows while far away.
 // Bounded: a tile whose producer has not delivered within ~4 s of wall clock gives up (returns false; the lattice gets
 // KA_ERR_INTERNAL) instead of hanging the GPU - this can only be a bug in the hand-off, never an input.
-__device__ __forceinline__ bool tp_wait_progress(gu32w_t word, uint32_t need, uint32_t have)
+// Hysteresis: a tile that does have to wait waits for `want` >= need (two blocks more): the poll it carries into a block
+// start is a block old, so a tile sitting exactly at the limit would pay a poll round trip (~1 us) at every block;
+// after one longer wait it stays ahead of its stale information for as long as it is not faster than its producer.
+__device__ __forceinline__ bool tp_wait_progress(gu32w_t word, uint32_t need, uint32_t want, uint32_t have)
 {
     if (have >= need) return true;
     const uint64_t t0 = wall_clock64();   // 100 MHz
     for (;;) {
-        const uint32_t gap = need - have;
+        const uint32_t gap = want - have;
         if (gap > 4096u) __builtin_amdgcn_s_sleep(127);
         else if (gap > 256u) __builtin_amdgcn_s_sleep(32);
         else __builtin_amdgcn_s_sleep(4);
@@ -135,7 +156,7 @@ __device__ __forceinline__ bool tp_wait_progress(gu32w_t word, uint32_t need, ui
         tp_prog_load(v, word);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) : : "memory");
         have = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-        if (have >= need) return true;
+        if (have >= want) return true;
         if (wall_clock64() - t0 > 400000000ull) return false;
     }
 }
@@ -213,12 +234,19 @@ __device__ __forceinline__ void tp_frame(TpTile<M, ZL> &c, uint32_t t, float (&H
                     const uint32_t nlo = (uint32_t)(dlo > 0 ? dlo : 0);
                     const uint32_t nhi = (c.L - nlo < c.B) ? c.L : nlo + c.B;
                     if (nlo != c.lo || nhi != c.hi) {
-                        c.lo = nlo;
-                        c.hi = nhi;
                         const bool was_edge = c.edge;
                         c.edge = (int32_t)nlo > c.base || (int32_t)nhi < c.base + kTpTile;
-                        if (c.edge || was_edge) tp_masks(c.mk, (int32_t)nlo - c.base, (int32_t)nhi - c.base);
-                        c.thr = 0;   // frame t+1 is the first of a new band: it must come through here again
+                        if (c.edge) {   // (the masks are kept up to date only while an edge is inside the tile)
+                            if (was_edge && nlo - c.lo <= 1u && nhi - c.hi <= 1u) {   // the usual step: one position leaves, one enters
+                                if (nlo != c.lo) tp_mask_toggle(c.mk, (int32_t)c.lo - c.base);
+                                if (nhi != c.hi) tp_mask_toggle(c.mk, (int32_t)c.hi - c.base);
+                            } else {
+                                tp_masks(c.mk, (int32_t)nlo - c.base, (int32_t)nhi - c.base);
+                            }
+                        }
+                        if (c.edge || was_edge) c.thr = 0;   // frame t+1 is the first of a new band: it must come through here again (rule ii)
+                        c.lo = nlo;
+                        c.hi = nhi;
                     }
                 }
             }
@@ -328,10 +356,12 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
     uint32_t issued_tb = 0;
     auto issue_block = [&](uint32_t tb) {
         issued_tb = tb;
+        // ONE path (see land_block): a running row pointer that stops at the lattice's last row
+        const char *rp = c.lp + (size_t)(tb < last_row ? tb : last_row) * c.ld;
 #pragma unroll
         for (int f = 0; f < kTpBlock; ++f) {
-            const uint32_t tt = tb + f < last_row ? tb + f : last_row;
-            row_reload(rows[f], c.lane_off, c.lp + (size_t)tt * c.ld);
+            row_reload(rows[f], c.lane_off, rp);
+            rp += tb + f < last_row ? c.ld : 0;
         }
         {
             uint32_t s = tb + (uint32_t)(lane & (kTpBlock - 1));
@@ -419,7 +449,8 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
         if (kb >= kb0 - 1) land_block(nslot, (verify & 2) ? 0u : younger);   // (KA_TP_VERIFY=2/3: full drain, to tell a counting error from a hand-off error)
         // retired: everything issued before the loads of block kb+1, i.e. the halo stores of blocks <= kb-2 = slots <= 16 (kb-1)
         if (kb >= kb0 + 2) tp_prog_store(c.prog_out, tb - kTpBlock + 1);
-        if (kb + 2 <= kb1 && fed) fed = tp_wait_progress(c.prog_in, need_for((uint32_t)((kb + 2) * kTpBlock)), (uint32_t)__builtin_amdgcn_readfirstlane((int)pv));
+        if (kb + 2 <= kb1 && fed)
+            fed = tp_wait_progress(c.prog_in, need_for((uint32_t)((kb + 2) * kTpBlock)), need_for((uint32_t)((kb + 4) * kTpBlock)), (uint32_t)__builtin_amdgcn_readfirstlane((int)pv));
         issue_block((uint32_t)((kb + 2) * kTpBlock));
         younger = 0;
         if (kb < kb0) continue;
