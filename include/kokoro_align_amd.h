@@ -124,6 +124,10 @@ int ka_engine_set_mode(ka_engine *e, int32_t mode);
 /* Per-kernel timing of the LAST enqueued batch, measured with HIP events recorded on the
  * launch stream: ms[0] label prep, ms[1] forward DP, ms[2] backtrace walk, ms[3] output
  * gathers (best_labels / best_scores).  Enable before the call; costs one event per kernel. */
+/* Diagnostics of the tiled form (with KA_TP_VERIFY=4 in the environment): per tile of the last batch, 8 values
+ * {descriptor, tile, t_in, t_end, ticks spent waiting for the tile below, ticks alive, waits, start tick}, 100 MHz
+ * ticks, in ticket order.  Returns the number of tiles written (at most max_tasks). */
+int ka_debug_tile_stats(ka_engine *e, uint64_t *out, int32_t max_tasks);
 int ka_engine_set_profiling(ka_engine *e, int32_t on);
 int ka_engine_last_kernel_ms(ka_engine *e, float ms[4]);
 

@@ -166,6 +166,7 @@ struct ka_engine {
     int32_t mode = KA_MODE_AUTO;
     int32_t n_simd = 1024;                 // SIMDs of the device = persistent workers of the tiled form
     std::vector<int32_t> wide_tiled;       // last batch: lattices in the tiled form that the exact kernels cannot redo
+    size_t dbg_tasks = 0, dbg_stats = 0, dbg_n_tasks = 0;   // last batch: workspace offsets of the tile tasks and their timing records
 };
 
 namespace {
@@ -414,6 +415,11 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
     off += align_up(zero_bytes);
     const size_t off_tasks = off;
     off += align_up(n_tasks * sizeof(ka::TileTask));
+    const size_t off_stats = off;
+    off += align_up(n_tasks * sizeof(ka::TpStats));
+    e->dbg_tasks = off_tasks;
+    e->dbg_stats = off_stats;
+    e->dbg_n_tasks = n_tasks;
     const size_t off_halo = off;
     const size_t ninf_bytes = n_tiled ? align_up((size_t)(ninf_slots + 2 * ka::kTpBlock) * 16) : 0;
     off += ninf_bytes;
@@ -591,11 +597,12 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
         uint32_t *d_prog = reinterpret_cast<uint32_t *>(e->ws + off_prog);
         ka::TileAux *d_aux = reinterpret_cast<ka::TileAux *>(e->ws + off_aux);
         uint32_t *d_ticket = reinterpret_cast<uint32_t *>(e->ws + off_ticket);
+        ka::TpStats *d_stats = reinterpret_cast<ka::TpStats *>(e->ws + off_stats);
         switch (max_move) {
-        case 1: hipLaunchKernelGGL((ka::forward_tp_kernel<1>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket, verify); break;
-        case 2: hipLaunchKernelGGL((ka::forward_tp_kernel<2>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket, verify); break;
-        case 3: hipLaunchKernelGGL((ka::forward_tp_kernel<3>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket, verify); break;
-        default: hipLaunchKernelGGL((ka::forward_tp_kernel<4>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket, verify); break;
+        case 1: hipLaunchKernelGGL((ka::forward_tp_kernel<1>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket, verify, d_stats); break;
+        case 2: hipLaunchKernelGGL((ka::forward_tp_kernel<2>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket, verify, d_stats); break;
+        case 3: hipLaunchKernelGGL((ka::forward_tp_kernel<3>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket, verify, d_stats); break;
+        default: hipLaunchKernelGGL((ka::forward_tp_kernel<4>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket, verify, d_stats); break;
         }
         form = kFormWaveCheckpointed;
     }
@@ -736,6 +743,26 @@ int ka_ctc_best_path_f32(ka_engine *e, const float *log_probs, int64_t T, int32_
                                         &best_labels, &best_scores, &total, &status, mem, stream);
     if (total_score) *total_score = total;
     return rc;
+}
+
+int ka_debug_tile_stats(ka_engine *e, uint64_t *out, int32_t max_tasks)
+{
+    if (!e || !out || max_tasks < 0) return fail(KA_ERR_BAD_ARGS, "ka_debug_tile_stats: bad arguments");
+    DeviceGuard guard;
+    KA_HIP(guard.enter(e->device));
+    const size_t n = std::min<size_t>(e->dbg_n_tasks, (size_t)max_tasks);
+    std::vector<ka::TileTask> tk(n);
+    std::vector<ka::TpStats> st(n);
+    if (n) {
+        KA_HIP(hipMemcpy(tk.data(), e->ws + e->dbg_tasks, n * sizeof(ka::TileTask), hipMemcpyDeviceToHost));
+        KA_HIP(hipMemcpy(st.data(), e->ws + e->dbg_stats, n * sizeof(ka::TpStats), hipMemcpyDeviceToHost));
+    }
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t *o = out + 8 * i;
+        o[0] = (uint64_t)tk[i].lat; o[1] = (uint64_t)tk[i].tile; o[2] = (uint64_t)tk[i].t_in; o[3] = (uint64_t)tk[i].t_end;
+        o[4] = st[i].wait_ticks; o[5] = st[i].total_ticks; o[6] = st[i].spins; o[7] = st[i].start_tick;
+    }
+    return (int)n;
 }
 
 int ka_log_softmax_f32(const float *logits, float *log_probs, int64_t T, int32_t V, int64_t ld_in, int64_t ld_out,

@@ -143,10 +143,14 @@ __device__ __forceinline__ void tp_prog_load(uint32_t &dst, gu32w_t word /* unif
 // Hysteresis: a tile that does have to wait waits for `want` >= need (two blocks more): the poll it carries into a block
 // start is a block old, so a tile sitting exactly at the limit would pay a poll round trip (~1 us) at every block;
 // after one longer wait it stays ahead of its stale information for as long as it is not faster than its producer.
-__device__ __forceinline__ bool tp_wait_progress(gu32w_t word, uint32_t need, uint32_t want, uint32_t have)
+struct TpStats {
+    unsigned long long wait_ticks, total_ticks, spins, start_tick;   // 100 MHz ticks (KA_TP_VERIFY & 4: ka_debug_tile_stats)
+};
+__device__ __forceinline__ bool tp_wait_progress(gu32w_t word, uint32_t need, uint32_t want, uint32_t have, TpStats &st)
 {
     if (have >= need) return true;
     const uint64_t t0 = wall_clock64();   // 100 MHz
+    ++st.spins;
     for (;;) {
         const uint32_t gap = want - have;
         if (gap > 4096u) __builtin_amdgcn_s_sleep(127);
@@ -156,8 +160,12 @@ __device__ __forceinline__ bool tp_wait_progress(gu32w_t word, uint32_t need, ui
         tp_prog_load(v, word);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) : : "memory");
         have = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-        if (have >= want) return true;
-        if (wall_clock64() - t0 > 400000000ull) return false;
+        const uint64_t waited = wall_clock64() - t0;
+        if (have >= want) {
+            st.wait_ticks += waited;
+            return true;
+        }
+        if (waited > 400000000ull) return false;
     }
 }
 
@@ -292,8 +300,9 @@ __device__ __forceinline__ void tp_checkpoint(TpTile<M, ZL> &c, uint32_t t_next 
 // ---------------------------------------------------------------------------------------
 template <int M, bool ZL>
 __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk, int32_t *meta, char *halo, gu32w_t prog, TileAux *aux,
-                                            uint32_t lds_rows, uint32_t lds_halo, int verify)
+                                            uint32_t lds_rows, uint32_t lds_halo, int verify, TpStats *stats_out)
 {
+    TpStats st = {0, 0, 0, (unsigned long long)wall_clock64()};
     const int lane = threadIdx.x;
     const float NINF = ninf();
     const uint64_t lane63 = 1ull << 63;
@@ -450,7 +459,7 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
         // retired: everything issued before the loads of block kb+1, i.e. the halo stores of blocks <= kb-2 = slots <= 16 (kb-1)
         if (kb >= kb0 + 2) tp_prog_store(c.prog_out, tb - kTpBlock + 1);
         if (kb + 2 <= kb1 && fed)
-            fed = tp_wait_progress(c.prog_in, need_for((uint32_t)((kb + 2) * kTpBlock)), need_for((uint32_t)((kb + 4) * kTpBlock)), (uint32_t)__builtin_amdgcn_readfirstlane((int)pv));
+            fed = tp_wait_progress(c.prog_in, need_for((uint32_t)((kb + 2) * kTpBlock)), need_for((uint32_t)((kb + 4) * kTpBlock)), (uint32_t)__builtin_amdgcn_readfirstlane((int)pv), st);
         issue_block((uint32_t)((kb + 2) * kTpBlock));
         younger = 0;
         if (kb < kb0) continue;
@@ -512,6 +521,10 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tp_prog_store(c.prog_out, kTpProgDone);
     }
+    if ((verify & 4) && lane == 0) {
+        st.total_ticks = wall_clock64() - st.start_tick;
+        *stats_out = st;
+    }
     // ---- terminal state: the HIGHEST live position of frame T-1 (align.py:99-101), over the tiles alive then ----
     if ((uint32_t)c.t_end == c.T) {
         tp_masks(c.mk, (int32_t)c.lo - c.base, (int32_t)c.hi - c.base);
@@ -557,7 +570,7 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
 constexpr unsigned kTpLdsRequest = 40 * 1024;
 template <int M>
 __global__ __launch_bounds__(64) void forward_tp_kernel(const Lattice *__restrict__ lats, const TileTask *__restrict__ tasks, int n_tasks,
-                                                        int32_t *meta, char *halo, uint32_t *prog, TileAux *aux, uint32_t *ticket, int verify)
+                                                        int32_t *meta, char *halo, uint32_t *prog, TileAux *aux, uint32_t *ticket, int verify, TpStats *stats)
 {
     extern __shared__ __attribute__((aligned(16))) char tp_lds[];
     const uint32_t lds_rows = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&tp_lds[0];
@@ -570,9 +583,9 @@ __global__ __launch_bounds__(64) void forward_tp_kernel(const Lattice *__restric
     const Lattice &d = lats[__builtin_amdgcn_readfirstlane(tk.lat)];
     const int flags = __builtin_amdgcn_readfirstlane(meta_of(meta, d.idx)[2]);
     if (flags & kFlagZeroLabel)
-        tp_run_tile<M, true>(d, tk, meta, halo, (gu32w_t)prog, aux, lds_rows, lds_halo, verify);
+        tp_run_tile<M, true>(d, tk, meta, halo, (gu32w_t)prog, aux, lds_rows, lds_halo, verify, stats + tix);
     else
-        tp_run_tile<M, false>(d, tk, meta, halo, (gu32w_t)prog, aux, lds_rows, lds_halo, verify);
+        tp_run_tile<M, false>(d, tk, meta, halo, (gu32w_t)prog, aux, lds_rows, lds_halo, verify, stats + tix);
 }
 
 }  // namespace ka
