@@ -121,6 +121,20 @@ int ka_batch_finish(ka_engine *e, float *total_score, int32_t *status);
 #define KA_MODE_TILED 4
 int ka_engine_set_mode(ka_engine *e, int32_t mode);
 
+/* How the checkpointed forms (KA_MODE_WAVE, KA_MODE_TILED) walk the best path back.
+ *   KA_BACKTRACE_SERIAL    one wavefront per lattice, chunk after chunk of 32 frames (the position a chunk is entered
+ *                          at comes out of the chunk above it): least work, right for thousands of lattices.
+ *   KA_BACKTRACE_PARALLEL  every chunk of every lattice at once: per chunk a map "position at its last frame -> rise
+ *                          over the chunk" is recomputed for the whole band, 32 maps are composed into a super-chunk map,
+ *                          the end position is run down the super-chunk maps and then, in parallel, down the chunk maps,
+ *                          which gives every chunk its entry position.  ~8x the work, ~60x shorter for a lone lattice.
+ *   KA_BACKTRACE_AUTO      (default) PARALLEL up to a few hundred lattices per call, else SERIAL.
+ * Results are identical. */
+#define KA_BACKTRACE_AUTO 0
+#define KA_BACKTRACE_SERIAL 1
+#define KA_BACKTRACE_PARALLEL 2
+int ka_engine_set_backtrace(ka_engine *e, int32_t how);
+
 /* Per-kernel timing of the LAST enqueued batch, measured with HIP events recorded on the
  * launch stream: ms[0] label prep, ms[1] forward DP, ms[2] backtrace walk, ms[3] output
  * gathers (best_labels / best_scores).  Enable before the call; costs one event per kernel. */
@@ -128,6 +142,10 @@ int ka_engine_set_mode(ka_engine *e, int32_t mode);
  * {descriptor, tile, t_in, t_end, ticks spent waiting for the tile below, ticks alive, waits, start tick}, 100 MHz
  * ticks, in ticket order.  Returns the number of tiles written (at most max_tasks). */
 int ka_debug_tile_stats(ka_engine *e, uint64_t *out, int32_t max_tasks);
+/* Diagnostics of the chunk-parallel backtrace: for the first lattice of the last batch, the best-path position at the
+ * last frame of every chunk followed by that of every super-chunk (returns how many values), and optionally its
+ * chunk maps (one row of ring-size bytes per chunk). */
+int ka_debug_chunk_entries(ka_engine *e, int32_t *out, int32_t max_entries, uint8_t *map0_out, int64_t map0_max);
 int ka_engine_set_profiling(ka_engine *e, int32_t on);
 int ka_engine_last_kernel_ms(ka_engine *e, float ms[4]);
 

@@ -32,7 +32,7 @@ EXPORTS = [
     "ka_engine_last_kernel_ms", "ka_log_softmax_f32", "ka_hash_logprobs_f32", "ka_hash_labels_i32",
     "ka_hash_logprobs_batch_f32", "ka_hash_labels_batch_i32", "ka_engine_set_mode", "ka_lstm_step_f32",
     "ka_lstm_layer_f32", "ka_window_energy_f32", "ka_stft_frames_f32", "ka_power_f32", "ka_power_to_db_f32",
-    "ka_debug_tile_stats",
+    "ka_debug_tile_stats", "ka_engine_set_backtrace", "ka_debug_chunk_entries",
 ]
 
 
@@ -46,7 +46,7 @@ def library_path():
 
 def build_library(force=False):
     """Compile the HIP library for gfx950 (cross-compiles without a GPU)."""
-    srcs = [os.path.join(_PKG, "csrc", f) for f in ("ka_engine.hip", "ka_kernels.hpp", "ka_tiled.hpp")]
+    srcs = [os.path.join(_PKG, "csrc", f) for f in ("ka_engine.hip", "ka_kernels.hpp", "ka_tiled.hpp", "ka_parallel_bt.hpp")]
     srcs.append(os.path.join(os.path.dirname(_PKG), "include", "kokoro_align_amd.h"))
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:
@@ -91,10 +91,14 @@ def load_library():
     L.ka_batch_finish.argtypes = [vp, vp, vp]
     L.ka_engine_set_mode.restype = ctypes.c_int
     L.ka_engine_set_mode.argtypes = [vp, i32]
+    L.ka_engine_set_backtrace.restype = ctypes.c_int
+    L.ka_engine_set_backtrace.argtypes = [vp, i32]
     L.ka_engine_set_profiling.restype = ctypes.c_int
     L.ka_engine_set_profiling.argtypes = [vp, i32]
     L.ka_engine_last_kernel_ms.restype = ctypes.c_int
     L.ka_engine_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    L.ka_debug_chunk_entries.restype = ctypes.c_int
+    L.ka_debug_chunk_entries.argtypes = [vp, vp, i32, vp, i64]
     L.ka_debug_tile_stats.restype = ctypes.c_int
     L.ka_debug_tile_stats.argtypes = [vp, vp, i32]
     L.ka_log_softmax_f32.restype = ctypes.c_int
@@ -176,6 +180,11 @@ class Engine:
         one wavefront each: few lattices, any band width)"""
         code = {"auto": 0, "wave": 1, "workgroup": 2, "wave_exact": 3, "tiled": 4}[mode] if isinstance(mode, str) else int(mode)
         check(self.lib.ka_engine_set_mode(self.handle, code), "ka_engine_set_mode")
+
+    def set_backtrace(self, how):
+        """'auto' | 'serial' (chunk after chunk) | 'parallel' (every chunk at once; ka_parallel_bt.hpp)"""
+        code = {"auto": 0, "serial": 1, "parallel": 2}[how] if isinstance(how, str) else int(how)
+        check(self.lib.ka_engine_set_backtrace(self.handle, code), "ka_engine_set_backtrace")
 
     def set_profiling(self, on=True):
         check(self.lib.ka_engine_set_profiling(self.handle, int(bool(on))), "ka_engine_set_profiling")

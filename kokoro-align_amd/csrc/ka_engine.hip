@@ -7,6 +7,7 @@
 #include "../../include/kokoro_align_amd.h"
 #include "ka_kernels.hpp"
 #include "ka_tiled.hpp"
+#include "ka_parallel_bt.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -70,7 +71,19 @@ struct Shape {
     uint32_t ck_mask = 1023;     // checkpoint row: position p at float index p & ck_mask
     size_t ck_pitch = 4096;      // bytes per checkpoint row
     size_t halo_bytes = 0;       // halo slots of all tile boundaries
+    bool par_bt = false;         // this call walks the lattice's chunks in parallel (ka_parallel_bt.hpp)
 };
+
+// chunk-parallel backtrace: chunk maps (a byte per ring slot and chunk), super-chunk maps (two bytes), entry positions
+inline int64_t chunks_of_T(int64_t T) { return (T - 1) / ka::kCkFrames + 1; }
+inline int64_t supers_of_T(int64_t T) { return (chunks_of_T(T) + ka::kSuperChunks - 1) / ka::kSuperChunks; }
+inline size_t par_bt_bytes(const Shape &sh)
+{
+    const size_t R = (sh.tiled ? sh.ck_pitch : 4096) / 4;
+    return align_up((size_t)chunks_of_T(sh.T) * R) + align_up((size_t)supers_of_T(sh.T) * R * 2) +
+           align_up((size_t)(chunks_of_T(sh.T) + supers_of_T(sh.T)) * 4);
+}
+
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
@@ -144,6 +157,7 @@ size_t lattice_ws_bytes(const Shape &sh)
     size_t b = align_up((size_t)sh.labx_len * 4) + bp_region_bytes(sh);
     if (!sh.fast && !sh.tiled) b += align_up((size_t)sh.L * 2 * sizeof(float) + (size_t)sh.L * 2);
     if (sh.tiled) b += sh.halo_bytes;
+    if (sh.par_bt) b += par_bt_bytes(sh);
     return b;
 }
 
@@ -164,8 +178,10 @@ struct ka_engine {
     int32_t *h_meta = nullptr;  // pinned, 4 ints per lattice
     bool pending = false;
     int32_t mode = KA_MODE_AUTO;
+    int32_t backtrace = KA_BACKTRACE_AUTO;
     int32_t n_simd = 1024;                 // SIMDs of the device = persistent workers of the tiled form
     std::vector<int32_t> wide_tiled;       // last batch: lattices in the tiled form that the exact kernels cannot redo
+    size_t dbg_entry = 0, dbg_entry_n = 0, dbg_map0 = 0, dbg_map0_bytes = 0;   // last batch, descriptor 0: chunk entries and chunk maps
     size_t dbg_tasks = 0, dbg_stats = 0, dbg_n_tasks = 0;   // last batch: workspace offsets of the tile tasks and their timing records
 };
 
@@ -223,6 +239,19 @@ void launch_forward(const ka::Lattice *d_lats, int n, int32_t *d_meta, hipStream
     hipLaunchKernelGGL((ka::forward_w16_kernel<M, true>), dim3(n), dim3(64), 0, s, d_lats, d_meta, only_flagged);
 }
 
+// chunk maps -> super-chunk maps -> entry position of every chunk -> every chunk walked at once (ka_parallel_bt.hpp)
+template <int M>
+void launch_parallel_bt(const ka::Lattice *d_lats, int n, int32_t *d_meta, hipStream_t s, unsigned total_chunks, unsigned max_seg, unsigned max_sup,
+                        unsigned max_w)
+{
+    hipLaunchKernelGGL((ka::chunk_map_kernel<M, false>), dim3(total_chunks, max_seg), dim3(64), 0, s, d_lats, d_meta, n);
+    hipLaunchKernelGGL((ka::chunk_map_kernel<M, true>), dim3(total_chunks, max_seg), dim3(64), 0, s, d_lats, d_meta, n);
+    hipLaunchKernelGGL(ka::compose_maps_kernel, dim3(std::min(64u, (max_w + 255u) / 256u), max_sup, (unsigned)n), dim3(256), 0, s, d_lats, d_meta);
+    hipLaunchKernelGGL(ka::chain_entries_kernel, dim3((unsigned)n), dim3(256), 0, s, d_lats, d_meta);
+    hipLaunchKernelGGL((ka::backtrace_rc_kernel<M, false, true>), dim3(total_chunks), dim3(64), 0, s, d_lats, d_meta, n);
+    hipLaunchKernelGGL((ka::backtrace_rc_kernel<M, true, true>), dim3(total_chunks), dim3(64), 0, s, d_lats, d_meta, n);
+}
+
 // exact kernels over lattices another forward kernel has flagged kFlagExact
 template <int M>
 void launch_forward_flagged(const ka::Lattice *d_lats, int n, int32_t *d_meta, hipStream_t s)
@@ -234,8 +263,8 @@ void launch_forward_flagged(const ka::Lattice *d_lats, int n, int32_t *d_meta, h
 template <int M>
 void launch_backtrace_rc(const ka::Lattice *d_lats, int n, int32_t *d_meta, hipStream_t s)
 {
-    hipLaunchKernelGGL((ka::backtrace_rc_kernel<M, false>), dim3(n), dim3(64), 0, s, d_lats, d_meta);
-    hipLaunchKernelGGL((ka::backtrace_rc_kernel<M, true>), dim3(n), dim3(64), 0, s, d_lats, d_meta);
+    hipLaunchKernelGGL((ka::backtrace_rc_kernel<M, false, false>), dim3(n), dim3(64), 0, s, d_lats, d_meta, n);
+    hipLaunchKernelGGL((ka::backtrace_rc_kernel<M, true, false>), dim3(n), dim3(64), 0, s, d_lats, d_meta, n);
 }
 
 }  // namespace
@@ -305,8 +334,11 @@ size_t ka_workspace_bytes(int32_t n, const int64_t *T, const int64_t *S, int32_t
         if (!shape_of(T[i], S[i], V, beam_size, max_move, sh)) return 0;
         size_t plain = lattice_ws_bytes(sh);
         plan_tiles(sh, V, beam_size, max_move);       // whichever form the call ends up in: the larger of the two
+        sh.par_bt = sh.fast;
+        plain = lattice_ws_bytes(sh);
         if (sh.tileable) {
             sh.tiled = true;
+            sh.par_bt = true;
             plain = std::max(plain, lattice_ws_bytes(sh));
             tasks += sh.t_in.size();
             ninf_slots = std::max<int64_t>(ninf_slots, sh.t_end[0]);
@@ -325,6 +357,15 @@ int ka_engine_set_mode(ka_engine *e, int32_t mode)
     if (mode != KA_MODE_AUTO && mode != KA_MODE_WAVE && mode != KA_MODE_WORKGROUP && mode != KA_MODE_WAVE_EXACT && mode != KA_MODE_TILED)
         return fail(KA_ERR_BAD_ARGS, "ka_engine_set_mode: unknown mode");
     e->mode = mode;
+    return KA_OK;
+}
+
+int ka_engine_set_backtrace(ka_engine *e, int32_t how)
+{
+    if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
+    if (how != KA_BACKTRACE_AUTO && how != KA_BACKTRACE_SERIAL && how != KA_BACKTRACE_PARALLEL)
+        return fail(KA_ERR_BAD_ARGS, "ka_engine_set_backtrace: unknown value");
+    e->backtrace = how;
     return KA_OK;
 }
 
@@ -347,6 +388,7 @@ int ka_engine_last_kernel_ms(ka_engine *e, float ms[4])
 // The tiled form pays off when the one-wavefront-per-lattice form leaves the chip idle: a lattice costs ~5 concurrently
 // running tile wavefronts (a 1000-wide band touches 4-5 tiles), the chip has 1024 SIMDs.  Measured crossover: DESIGN.md.
 constexpr int32_t kAutoTiledMaxLattices = 160;
+constexpr int32_t kAutoParallelBacktraceMaxLattices = 512;
 
 static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, const int64_t *T, int32_t V,
                         const int64_t *ld, const int32_t *const *labels, const int64_t *S, int32_t beam_size,
@@ -393,6 +435,18 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
         }
     }
 
+    // ---- chunk-parallel backtrace (ka_parallel_bt.hpp) for the checkpointed results when the lattices are too few to
+    // fill the chip with one backtrace wavefront each (it recomputes the whole band of every chunk, ~8x the serial
+    // form's work, but all chunks at once)
+    {
+        int32_t n_ck = 0;   // lattices that end in backtrace_rc
+        for (int32_t i = 0; i < n; ++i)
+            n_ck += (sh[i].tiled || (sh[i].fast && e->mode != KA_MODE_WORKGROUP && e->mode != KA_MODE_WAVE_EXACT && sh[i].T < (int64_t(1) << 26))) ? 1 : 0;
+        const bool par = e->backtrace == KA_BACKTRACE_PARALLEL || (e->backtrace == KA_BACKTRACE_AUTO && n_ck <= kAutoParallelBacktraceMaxLattices);
+        for (int32_t i = 0; i < n; ++i)
+            sh[i].par_bt = par && (sh[i].tiled || (sh[i].fast && e->mode != KA_MODE_WORKGROUP && e->mode != KA_MODE_WAVE_EXACT));
+    }
+
     // ---- carve the workspace ----
     size_t off = 0;
     const size_t off_desc = off;
@@ -423,7 +477,7 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
     const size_t off_halo = off;
     const size_t ninf_bytes = n_tiled ? align_up((size_t)(ninf_slots + 2 * ka::kTpBlock) * 16) : 0;
     off += ninf_bytes;
-    struct Carve { size_t labx, bp, col, halo, lp, lab, path, labo, sco; };
+    struct Carve { size_t labx, bp, col, halo, map0, map1, entry, lp, lab, path, labo, sco; };
     std::vector<Carve> cv(n);
     for (int32_t i = 0; i < n; ++i) {
         cv[i].labx = off;
@@ -434,6 +488,15 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
         if (!sh[i].fast && !sh[i].tiled) off += align_up((size_t)sh[i].L * 2 * sizeof(float) + (size_t)sh[i].L * 2);
         cv[i].halo = off;
         if (sh[i].tiled) off += sh[i].halo_bytes;
+        cv[i].map0 = cv[i].map1 = cv[i].entry = off;
+        if (sh[i].par_bt) {
+            const size_t R = (sh[i].tiled ? sh[i].ck_pitch : 4096) / 4;
+            off += align_up((size_t)chunks_of_T(sh[i].T) * R);
+            cv[i].map1 = off;
+            off += align_up((size_t)supers_of_T(sh[i].T) * R * 2);
+            cv[i].entry = off;
+            off += align_up((size_t)(chunks_of_T(sh[i].T) + supers_of_T(sh[i].T)) * 4);
+        }
         if (mem == KA_MEM_HOST) {
             cv[i].lp = off;
             off += align_up((size_t)sh[i].T * (size_t)V * 4);
@@ -465,10 +528,13 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
     ka::Lattice *h_lats = reinterpret_cast<ka::Lattice *>(e->pin);
     e->h_meta = reinterpret_cast<int32_t *>(e->pin + align_up((size_t)n * sizeof(ka::Lattice)));
     ka::TileTask *h_tasks = reinterpret_cast<ka::TileTask *>(e->pin + align_up((size_t)n * sizeof(ka::Lattice)) + align_up((size_t)n * 16));
+    int64_t chunk_cursor = 0;
     for (int32_t k = 0; k < n; ++k) {
         const int32_t i = order[k];
         ka::Lattice &d = h_lats[k];
         std::memset(&d, 0, sizeof(d));
+        d.chunk0 = chunk_cursor;
+        chunk_cursor += chunks_of_T(sh[i].T);
         if (mem == KA_MEM_HOST) {
             d.lp = reinterpret_cast<const float *>(e->ws + cv[i].lp);
             d.labels = reinterpret_cast<const int32_t *>(e->ws + cv[i].lab);
@@ -499,6 +565,15 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
         d.n_final = sh[i].tiled ? sh[i].n_final : 0;
         d.ck_mask = sh[i].tiled ? sh[i].ck_mask : 1023u;
         d.ck_pitch = sh[i].tiled ? (int32_t)sh[i].ck_pitch : 4096;
+        d.map0 = reinterpret_cast<uint8_t *>(e->ws + cv[i].map0);
+        d.map1 = reinterpret_cast<uint16_t *>(e->ws + cv[i].map1);
+        d.entry = reinterpret_cast<int32_t *>(e->ws + cv[i].entry);
+        if (k == 0) {
+            e->dbg_entry = cv[i].entry;
+            e->dbg_entry_n = sh[i].par_bt ? (size_t)(chunks_of_T(sh[i].T) + supers_of_T(sh[i].T)) : 0;
+            e->dbg_map0 = cv[i].map0;
+            e->dbg_map0_bytes = sh[i].par_bt ? (size_t)chunks_of_T(sh[i].T) * ((sh[i].tiled ? sh[i].ck_pitch : 4096) / 4) : 0;
+        }
         if (sh[i].tiled && !sh[i].fast) e->wide_tiled.push_back(i);
     }
     // ---- tile tasks, sorted by first frame (then tile, then lattice): a tile's producer holds an earlier ticket ----
@@ -636,11 +711,34 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
     // the walk; [rc_lo, rc_hi) = descriptors whose outputs backtrace_rc writes itself
     const int32_t rc_lo = 0, rc_hi = n_tiled + (form == kFormWaveCheckpointed ? n_fast : 0);
     if (rc_hi > rc_lo) {
-        switch (max_move) {
-        case 1: launch_backtrace_rc<1>(d_lats + rc_lo, rc_hi - rc_lo, d_meta, stream); break;
-        case 2: launch_backtrace_rc<2>(d_lats + rc_lo, rc_hi - rc_lo, d_meta, stream); break;
-        case 3: launch_backtrace_rc<3>(d_lats + rc_lo, rc_hi - rc_lo, d_meta, stream); break;
-        default: launch_backtrace_rc<4>(d_lats + rc_lo, rc_hi - rc_lo, d_meta, stream); break;
+        // chunk-parallel form: every descriptor of the range carries its maps (par_bt was decided per call)
+        int64_t total_chunks = 0, max_seg = 1, max_sup = 1, max_w = 1;
+        bool par = true;
+        for (int32_t k = rc_lo; k < rc_hi; ++k) {
+            const Shape &p = sh[order[k]];
+            par = par && p.par_bt;
+            total_chunks += chunks_of_T(p.T);
+            max_seg = std::max<int64_t>(max_seg, (p.W + 7 + ka::kCmOut - 1) / ka::kCmOut);
+            max_sup = std::max<int64_t>(max_sup, supers_of_T(p.T));
+            max_w = std::max<int64_t>(max_w, p.W);
+        }
+        par = par && max_seg <= 65535 && max_sup <= 65535 && total_chunks < (int64_t(1) << 31) && rc_hi - rc_lo <= 65535;
+        if (par) {
+            const unsigned gc = (unsigned)total_chunks, gs = (unsigned)max_seg;
+            const int nl = rc_hi - rc_lo;
+            switch (max_move) {
+            case 1: launch_parallel_bt<1>(d_lats + rc_lo, nl, d_meta, stream, gc, gs, (unsigned)max_sup, (unsigned)max_w); break;
+            case 2: launch_parallel_bt<2>(d_lats + rc_lo, nl, d_meta, stream, gc, gs, (unsigned)max_sup, (unsigned)max_w); break;
+            case 3: launch_parallel_bt<3>(d_lats + rc_lo, nl, d_meta, stream, gc, gs, (unsigned)max_sup, (unsigned)max_w); break;
+            default: launch_parallel_bt<4>(d_lats + rc_lo, nl, d_meta, stream, gc, gs, (unsigned)max_sup, (unsigned)max_w); break;
+            }
+        } else {
+            switch (max_move) {
+            case 1: launch_backtrace_rc<1>(d_lats + rc_lo, rc_hi - rc_lo, d_meta, stream); break;
+            case 2: launch_backtrace_rc<2>(d_lats + rc_lo, rc_hi - rc_lo, d_meta, stream); break;
+            case 3: launch_backtrace_rc<3>(d_lats + rc_lo, rc_hi - rc_lo, d_meta, stream); break;
+            default: launch_backtrace_rc<4>(d_lats + rc_lo, rc_hi - rc_lo, d_meta, stream); break;
+            }
         }
         hipLaunchKernelGGL(ka::backtrace_w16_kernel, dim3(rc_hi - rc_lo), dim3(64), 0, stream, d_lats + rc_lo, d_meta, 1);
     }
@@ -743,6 +841,18 @@ int ka_ctc_best_path_f32(ka_engine *e, const float *log_probs, int64_t T, int32_
                                         &best_labels, &best_scores, &total, &status, mem, stream);
     if (total_score) *total_score = total;
     return rc;
+}
+
+int ka_debug_chunk_entries(ka_engine *e, int32_t *out, int32_t max_entries, uint8_t *map0_out, int64_t map0_max)
+{
+    if (!e || !out || max_entries < 0) return fail(KA_ERR_BAD_ARGS, "ka_debug_chunk_entries: bad arguments");
+    DeviceGuard guard;
+    KA_HIP(guard.enter(e->device));
+    const size_t n = std::min<size_t>(e->dbg_entry_n, (size_t)max_entries);
+    if (n) KA_HIP(hipMemcpy(out, e->ws + e->dbg_entry, n * 4, hipMemcpyDeviceToHost));
+    if (map0_out && map0_max > 0 && e->dbg_map0_bytes)
+        KA_HIP(hipMemcpy(map0_out, e->ws + e->dbg_map0, std::min<size_t>(e->dbg_map0_bytes, (size_t)map0_max), hipMemcpyDeviceToHost));
+    return (int)n;
 }
 
 int ka_debug_tile_stats(ka_engine *e, uint64_t *out, int32_t max_tasks)

@@ -90,6 +90,11 @@ struct Lattice {
     // holds every tile the band can touch, or the whole label axis)
     uint32_t ck_mask;
     int32_t ck_pitch;       // bytes
+    // chunk-parallel backtrace (ka_parallel_bt.hpp), rows addressed like the checkpoints (position p at p & ck_mask):
+    uint8_t *map0;          // [chunk c][ck_pitch / 4]: how far the best path into position p of frame 32c+31 has risen since frame 32c-1
+    uint16_t *map1;         // [super-chunk s][ck_pitch / 4]: the same over the 32 chunks of a super-chunk
+    int32_t *entry;         // [chunks]: best-path position at the last frame of every chunk, then [super-chunks]: of every super-chunk
+    int64_t chunk0;         // index of this lattice's chunk 0 among the chunks of the launch
 };
 
 // meta[4*idx + {0,1,2,3}] = status, end position, flags (bit0: a transcript label is 0), total score bits
@@ -1496,10 +1501,27 @@ __device__ __forceinline__ uint64_t lane_field(uint32_t count, uint32_t first)
 constexpr int kRcLanes = 62;   // lanes 62 and 63 are kept at -inf: they are the "nothing below position 0" that
                                // wave_ror hands to lanes 0 and 1 (window width 124 >= 97 + slack)
 
-template <int M, bool ZL>
-__global__ __launch_bounds__(64) void backtrace_rc_kernel(const Lattice *__restrict__ lats, const int32_t *meta)
+// Chunks of all lattices of a launch are numbered consecutively (Lattice::chunk0 = a lattice's first): which lattice
+// does chunk `g` belong to?  (wave-uniform binary search over the descriptors)
+__device__ __forceinline__ int lattice_of_chunk(const Lattice *__restrict__ lats, int n, int64_t g)
 {
-    const Lattice &d = lats[blockIdx.x];
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (lats[mid].chunk0 <= g) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+__device__ __forceinline__ int chunks_of(int T) { return (T - 1) / kCkFrames + 1; }
+
+// PAR = false: one wavefront per lattice walks its chunks from the last to the first (the position a chunk is entered
+// at comes out of the chunk above it).  PAR = true: one wavefront per CHUNK, entered at Lattice::entry[chunk], which the
+// chunk-parallel backtrace (ka_parallel_bt.hpp) has worked out for every chunk beforehand; grid = all chunks of the launch.
+template <int M, bool ZL, bool PAR>
+__global__ __launch_bounds__(64) void backtrace_rc_kernel(const Lattice *__restrict__ lats, const int32_t *meta, int n_lats)
+{
+    const int which = PAR ? __builtin_amdgcn_readfirstlane(lattice_of_chunk(lats, n_lats, (int64_t)blockIdx.x)) : (int)blockIdx.x;
+    const Lattice &d = lats[which];
     const int lane = threadIdx.x;
     const int32_t *mt = meta + 4 * (size_t)d.idx;
     const int flags = __builtin_amdgcn_readfirstlane(mt[2]);
@@ -1527,6 +1549,11 @@ __global__ __launch_bounds__(64) void backtrace_rc_kernel(const Lattice *__restr
 
     // floor(L*t/T) and remainder at the start of the last chunk; one chunk back = minus (32*L)/T, (32*L)%T
     uint32_t t0 = ((T - 1) / kCkFrames) * kCkFrames;
+    if constexpr (PAR) {
+        const uint32_t c = (uint32_t)((int64_t)blockIdx.x - d.chunk0);
+        t0 = c * kCkFrames;
+        p = __builtin_amdgcn_readfirstlane(d.entry[c]);
+    }
     // (64-bit divisions run on the vector unit: tell the compiler the results are wave-uniform)
     const auto uni = [](uint64_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v); };
     uint32_t q0 = uni(((uint64_t)L * t0) / T), r0 = uni(((uint64_t)L * t0) % T);
@@ -1663,7 +1690,7 @@ __global__ __launch_bounds__(64) void backtrace_rc_kernel(const Lattice *__restr
             }
         }
         p = qq + wlo;
-        if (t0 == 0) break;
+        if (PAR || t0 == 0) break;
         t0 -= kCkFrames;
         q0 -= D32;
         if (r0 < R32) { r0 += T; q0 -= 1; }

@@ -1,0 +1,343 @@
+// ka_parallel_bt.hpp — chunk-parallel backtrace for the checkpointed forms.
+//
+// backtrace_rc_kernel<.., PAR = false> walks a lattice's 32-frame chunks one after the other, because the position at
+// which the best path enters a chunk is only known once the chunk above it has been walked: 5 us per chunk, 8 ms for a
+// 50 000-frame lattice - as long as the whole forward pass - with one wavefront busy.  Here every chunk is walked at the
+// same time.  What makes that possible is the MAP of a chunk: for EVERY position p the band holds at the chunk's last
+// frame, how far the best path into p has risen since the last frame of the chunk before (0..96 positions; for the
+// cell that is on the best path of the lattice this is exactly what the walk would find).  Maps need no entry position:
+//   1. chunk_map_kernel      one wavefront per (chunk, 408-position segment of its band): the chunk is recomputed forward
+//                            from its checkpoint with the reference's exact first-max rule (align.py:83), and every cell
+//                            carries along the position its best path had at the chunk's start ("origin"); 8 cells per
+//                            lane, 512 positions per wavefront of which the lowest 96 only warm up (what is unknown below
+//                            the window climbs 3 positions per frame, exactly as in backtrace_rc).
+//   2. compose_maps_kernel   32 chunk maps -> one super-chunk map (1024 frames): one thread per band position.
+//   3. chain_entries_kernel  one workgroup per lattice: the end position runs down the super-chunk maps (a few dozen
+//                            dependent loads), then every super-chunk runs its own 32 chunk maps: the entry position of
+//                            every chunk.
+//   4. backtrace_rc_kernel<.., PAR = true>   one wavefront per chunk, all chunks of the launch at once.
+// Bit-exact by construction: the maps are made of the same float operations, in the same order, as the forward kernels and
+// the reference; the parity suite runs in this form too (KA_MODE_* x parallel backtrace).
+#pragma once
+#include "ka_kernels.hpp"
+
+namespace ka {
+
+constexpr int kCmCells = 8;                      // cells per lane
+constexpr int kCmSpan = 64 * kCmCells;           // positions a wavefront recomputes
+constexpr int kCmWarm = 96;                      // lowest positions of the window: warm-up only (3 positions x 32 frames)
+constexpr int kCmOut = 408;                      // positions a wavefront delivers (a multiple of 8, <= kCmSpan - kCmWarm - 7)
+constexpr int kSuperChunks = 32;                 // chunks per super-chunk
+static_assert(kCmWarm == 3 * kCkFrames && kCmOut % 8 == 0 && kCmOut + kCmWarm <= kCmSpan, "window geometry");
+
+__device__ __forceinline__ int supers_of(int n_chunks) { return (n_chunks + kSuperChunks - 1) / kSuperChunks; }
+__device__ __forceinline__ int chunk_last_frame(int c, int T) { return min(c * kCkFrames + kCkFrames - 1, T - 1); }
+// band of frame t (align.py:64-65), 64-bit like the reference
+__device__ __forceinline__ void band_of(uint32_t L, uint32_t T, uint32_t B, uint32_t t, uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t q = (uint32_t)(((uint64_t)L * t) / T);
+    const int32_t d = (int32_t)q - (int32_t)(B >> 1);
+    lo = (uint32_t)(d > 0 ? d : 0);
+    hi = (L - lo < B) ? L : lo + B;
+}
+__device__ __forceinline__ float select_f(float a, float b, uint64_t mask) { return select_by_mask(a, b, mask); }
+__device__ __forceinline__ int select_i(int a, int b, uint64_t mask)
+{
+    int r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+    return r;
+}
+// a pointer the compiler cannot prove wave-uniform (it came out of a search loop), for an "s" operand of inline asm
+// (v_readfirstlane is a VALU write of an SGPR, and a vector-memory instruction needs FIVE wait states before it may
+//  read such an SGPR; hipcc pads its own instructions but cannot see into an asm statement - without the s_nop the load
+//  used the registers' previous contents: the pointer without its offset)
+template <class P>
+__device__ __forceinline__ P uniform_ptr(P p)
+{
+    const uint64_t v = (uint64_t)p;
+    uint64_t w = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    asm volatile("s_nop 4" : "+s"(w));
+    return (P)w;
+}
+__device__ __forceinline__ int wave_shr1_i(int first, int x) { return __builtin_amdgcn_update_dpp(first, x, 0x138, 0xF, 0xF, false); }
+
+// one label cell with origin: candidates a_j + e in move order, the first one that attains the maximum wins
+template <int M, bool ZL>
+__device__ __forceinline__ void cm_label(float a0, float a1, float a2, float a3, int o0, int o1, int o2, int o3, float e, float veto, float &s, int &o)
+{
+    const float c0 = a0 + e;
+    if constexpr (M == 1) {
+        s = c0;
+        o = o0;
+    } else {
+        const float c1 = a1 + e;
+        if constexpr (M == 2) {
+            s = __builtin_fmaxf(c0, c1);
+            o = select_i(o1, o0, feq(c0, s));
+        } else {
+            float c2 = a2 + e;
+            if constexpr (ZL) c2 = __builtin_fminf(c2, veto);
+            if constexpr (M == 3) {
+                s = __builtin_fmaxf(__builtin_fmaxf(c0, c1), c2);
+                o = select_i(select_i(o2, o1, feq(c1, s)), o0, feq(c0, s));
+            } else {
+                const float c3 = a3 + e;
+                s = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(c0, c1), c2), c3);
+                o = select_i(select_i(select_i(o3, o2, feq(c2, s)), o1, feq(c1, s)), o0, feq(c0, s));
+            }
+        }
+    }
+}
+// one blank cell: moves {0, 1, 3} (move 2 is vetoed on blanks, align.py:80-81)
+template <int M>
+__device__ __forceinline__ void cm_blank(float a0, float a1, float a3, int o0, int o1, int o3, float e, float &s, int &o)
+{
+    const float c0 = a0 + e;
+    if constexpr (M == 1) {
+        s = c0;
+        o = o0;
+    } else {
+        const float c1 = a1 + e;
+        if constexpr (M <= 3) {
+            s = __builtin_fmaxf(c0, c1);
+            o = select_i(o1, o0, feq(c0, s));
+        } else {
+            const float c3 = a3 + e;
+            s = __builtin_fmaxf(__builtin_fmaxf(c0, c1), c3);
+            o = select_i(select_i(o3, o1, feq(c1, s)), o0, feq(c0, s));
+        }
+    }
+}
+struct CmMasks {
+    uint64_t m[kCmCells];   // m[k]: lanes whose cell k (position w0 + 8 lane + k) is inside the band
+};
+__device__ __forceinline__ void cm_masks(CmMasks &mk, int32_t lo_rel, int32_t hi_rel)
+{
+    lo_rel = lo_rel < -16 ? -16 : (lo_rel > kCmSpan + 16 ? kCmSpan + 16 : lo_rel);
+    hi_rel = hi_rel < -16 ? -16 : (hi_rel > kCmSpan + 16 ? kCmSpan + 16 : hi_rel);
+#pragma unroll
+    for (int k = 0; k < kCmCells; ++k) {
+        // lanes l with lo_rel <= 8 l + k < hi_rel
+        int a = (lo_rel - k + 7) >> 3, b = (hi_rel - k + 7) >> 3;
+        a = a < 0 ? 0 : (a > 64 ? 64 : a);
+        b = b < 0 ? 0 : (b > 64 ? 64 : b);
+        const uint32_t n = b > a ? (uint32_t)(b - a) : 0u;
+        mk.m[k] = n == 0 ? 0ull : ((n >= 64u ? ~0ull : ((1ull << n) - 1ull)) << a);
+    }
+}
+
+// grid: x = chunk (numbered over all lattices of the launch), y = segment of the band
+template <int M, bool ZL>
+__global__ __launch_bounds__(64) void chunk_map_kernel(const Lattice *__restrict__ lats, const int32_t *meta, int n_lats)
+{
+    const Lattice &d = lats[__builtin_amdgcn_readfirstlane(lattice_of_chunk(lats, n_lats, (int64_t)blockIdx.x))];
+    const int lane = threadIdx.x;
+    const int32_t *mt = meta + 4 * (size_t)__builtin_amdgcn_readfirstlane(d.idx);
+    const int flags = __builtin_amdgcn_readfirstlane(mt[2]);
+    if (flags & (kFlagExact | kFlagDeclined)) return;
+    if (((flags & kFlagZeroLabel) != 0) != ZL) return;
+    if (__builtin_amdgcn_readfirstlane(mt[0]) != kStatusOk || __builtin_amdgcn_readfirstlane(mt[1]) < 0) return;
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((int64_t)blockIdx.x - d.chunk0));
+    if (c == 0) return;                                   // nothing lies before chunk 0
+    const uint32_t T = (uint32_t)__builtin_amdgcn_readfirstlane(d.T);
+    const uint32_t L = (uint32_t)__builtin_amdgcn_readfirstlane(d.L);
+    const uint32_t B = (uint32_t)__builtin_amdgcn_readfirstlane(d.beam);
+    const float NINF = ninf();
+    const uint32_t t0 = c * kCkFrames, te = (uint32_t)chunk_last_frame((int)c, (int)T);
+    const auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    // band of the chunk's last frame and this wavefront's segment of it
+    uint32_t lo_e, hi_e;
+    band_of(L, T, B, te, lo_e, hi_e);
+    lo_e = uni(lo_e);
+    hi_e = uni(hi_e);
+    const uint32_t seg_lo = (lo_e & ~7u) + (uint32_t)blockIdx.y * kCmOut;
+    if (seg_lo >= hi_e) return;
+    const uint32_t w0 = uni(seg_lo > (uint32_t)kCmWarm ? seg_lo - kCmWarm : 0u);   // first position of the window (a multiple of 8); scalar from here on
+    const uint32_t ck_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.ck_mask);
+    const size_t ck_pitch = (size_t)(uint32_t)__builtin_amdgcn_readfirstlane(d.ck_pitch);
+    const uint32_t p_lane = w0 + (uint32_t)kCmCells * (uint32_t)lane;         // the lane's first position
+
+    // ---- loads: labels, checkpoint, the chunk's rows (inline asm, counted waits: as in backtrace_rc) ----
+    const char *lp = reinterpret_cast<const char *>(d.lp);
+    const size_t ldb = (size_t)d.ld * 4;
+    const uint32_t col_off = (lane < d.V ? (uint32_t)lane : 0u) * 4u;
+    v4i_t lab4;   // 4 * label of the lane's label cells (positions p_lane + 1, 3, 5, 7); labx is zero padded past S
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(lab4) : "v"((uint32_t)lane * 16u), "s"(uniform_ptr((gci32_t)d.labx + (w0 >> 1))) : "memory");
+    f32x4 ck0, ck1;   // scores of the lane's 8 positions after frame t0 - 1
+    {
+        const uint32_t off = (p_lane & ck_mask) * 4u;   // (p_lane is a multiple of 8: the 8 cells do not wrap)
+        const char *row = uniform_ptr(reinterpret_cast<const char *>(d.bp) + ((size_t)c - 1) * ck_pitch);
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ck0) : "v"(off), "s"(row) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(ck1) : "v"(off), "s"(row) : "memory");
+    }
+    const int n = (int)(te - t0 + 1);
+    // the chunk's rows go through LDS (lane = column): the frame loop below stays a loop (unrolled 32 times with the rows
+    // in registers it is 280 KB of code per instance), and an emission is one ds_read_b32
+    __shared__ float s_rows[kCkFrames][64];
+    {
+        float rows[kCkFrames];
+        const char *rp = uniform_ptr(lp + (size_t)t0 * ldb);
+#pragma unroll
+        for (int f = 0; f < kCkFrames; ++f) {
+            rows[f] = row_load(col_off, rp);
+            rp += (f + 1 < n) ? ldb : 0;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(lab4), "+v"(ck0), "+v"(ck1) : : "memory");
+#pragma unroll
+        for (int f = 0; f < kCkFrames; ++f) {
+            asm volatile("" : "+v"(rows[f]) : : "memory");
+            s_rows[f][lane] = rows[f];
+        }
+    }
+    const int la[4] = {lab4.x, lab4.y, lab4.z, lab4.w};
+    float veto[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) veto[i] = (ZL && la[i] == 0) ? NINF : __builtin_inff();
+
+    // ---- state: scores sc[k], origins og[k] (window-relative position at the chunk's start) ----
+    uint32_t q, rem;   // floor(L t / T) and remainder of the frame being computed
+    const uint32_t dq = L / T, dr = L % T;
+    {
+        const uint64_t x = (uint64_t)L * (t0 - 1);   // band of frame t0 - 1 limits the checkpoint
+        q = uni((uint32_t)(x / T));
+        rem = uni((uint32_t)(x % T));
+    }
+    uint32_t lo, hi;
+    {
+        const int32_t dl = (int32_t)q - (int32_t)(B >> 1);
+        lo = (uint32_t)(dl > 0 ? dl : 0);
+        hi = (L - lo < B) ? L : lo + B;
+    }
+    CmMasks mk;
+    cm_masks(mk, (int32_t)lo - (int32_t)w0, (int32_t)hi - (int32_t)w0);
+    float sc[kCmCells] = {ck0[0], ck0[1], ck0[2], ck0[3], ck1[0], ck1[1], ck1[2], ck1[3]};
+    int og[kCmCells];
+#pragma unroll
+    for (int k = 0; k < kCmCells; ++k) {
+        sc[k] = select_f(NINF, sc[k], mk.m[k]);
+        og[k] = kCmCells * lane + k;
+    }
+    for (int f = 0; f < n; ++f) {
+        {
+            // band of frame t0 + f
+            rem += dr;
+            q += dq;
+            if (rem >= T) { rem -= T; ++q; }
+            {
+                const int32_t dl = (int32_t)q - (int32_t)(B >> 1);
+                const uint32_t nlo = (uint32_t)(dl > 0 ? dl : 0);
+                const uint32_t nhi = (L - nlo < B) ? L : nlo + B;
+                if (nlo != lo || nhi != hi) {
+                    lo = nlo;
+                    hi = nhi;
+                    cm_masks(mk, (int32_t)lo - (int32_t)w0, (int32_t)hi - (int32_t)w0);
+                }
+            }
+            const float e0 = s_rows[f][0];
+            float el[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) el[i] = lds_col(&s_rows[f][0], la[i]);
+            // the three cells below the lane's first one (lane 0: nothing is known below the window)
+            const float h1 = wave_shr1(NINF, sc[7]), h2 = wave_shr1(NINF, sc[6]), h3 = wave_shr1(NINF, sc[5]);
+            const int g1 = wave_shr1_i(0, og[7]), g2 = wave_shr1_i(0, og[6]), g3 = wave_shr1_i(0, og[5]);
+            // cells 7..0 in place: a cell reads the old values of itself and of the three cells below it
+#pragma unroll
+            for (int i = 3; i >= 0; --i) {
+                const int kb = 2 * i, kl = 2 * i + 1;   // blank and label cell of pair i
+                const float b_0 = sc[kb], l_0 = sc[kl];
+                const int ob_0 = og[kb], ol_0 = og[kl];
+                // positions kb-1, kb-2, kb-3 of the lane (negative: the lane below, cells 7, 6, 5)
+                const float p1 = i > 0 ? sc[i > 0 ? kb - 1 : 0] : h1, p2 = i > 0 ? sc[i > 0 ? kb - 2 : 0] : h2;
+                const float p3 = i > 1 ? sc[i > 1 ? kb - 3 : 0] : (i == 1 ? h1 : h3);
+                const int q1 = i > 0 ? og[i > 0 ? kb - 1 : 0] : g1, q2 = i > 0 ? og[i > 0 ? kb - 2 : 0] : g2;
+                const int q3 = i > 1 ? og[i > 1 ? kb - 3 : 0] : (i == 1 ? g1 : g3);
+                float s;
+                int o;
+                cm_label<M, ZL>(l_0, b_0, p1, p2, ol_0, ob_0, q1, q2, el[i], veto[i], s, o);
+                sc[kl] = select_f(NINF, s, mk.m[kl]);
+                og[kl] = o;
+                cm_blank<M>(b_0, p1, p3, ob_0, q1, q3, e0, s, o);
+                sc[kb] = select_f(NINF, s, mk.m[kb]);
+                og[kb] = o;
+            }
+        }
+    }
+    // ---- the map: rise of every cell of this segment over the chunk, one byte per position ----
+    {
+        const uint32_t rel0 = seg_lo - w0;                                   // first delivered window position
+        const uint32_t r = (uint32_t)kCmCells * (uint32_t)lane;
+        const bool mine = r >= rel0 && r < rel0 + kCmOut && p_lane < hi_e;   // (hi_e need not be a multiple of 8: the last group is cut by the band)
+        uint32_t w[2] = {0, 0};
+#pragma unroll
+        for (int k = 0; k < kCmCells; ++k) {
+            int rise = (int)r + k - og[k];
+            rise = rise < 0 ? 0 : (rise > 255 ? 255 : rise);
+            w[k >> 2] |= (uint32_t)rise << (8 * (k & 3));
+        }
+        if (mine) {
+            uint8_t *row = d.map0 + (size_t)c * (ck_pitch / 4);
+            *reinterpret_cast<uint2 *>(row + (p_lane & ck_mask)) = make_uint2(w[0], w[1]);
+        }
+    }
+}
+
+// 32 chunk maps -> one super-chunk map.  grid: x = blocks of 256 band positions, y = super-chunk, z = lattice
+__global__ __launch_bounds__(256) void compose_maps_kernel(const Lattice *__restrict__ lats, const int32_t *meta)
+{
+    const Lattice &d = lats[blockIdx.z];
+    const int32_t *mt = meta + 4 * (size_t)d.idx;
+    if ((mt[2] & (kFlagExact | kFlagDeclined)) || mt[0] != kStatusOk || mt[1] < 0) return;
+    const int T = d.T, nck = chunks_of(T), nsup = supers_of(nck);
+    const int s = blockIdx.y;
+    if (s == 0 || s >= nsup) return;
+    const int c_hi = min(s * kSuperChunks + kSuperChunks, nck) - 1, c_lo = s * kSuperChunks;
+    uint32_t lo, hi;
+    band_of((uint32_t)d.L, (uint32_t)T, (uint32_t)d.beam, (uint32_t)chunk_last_frame(c_hi, T), lo, hi);
+    const size_t R = (size_t)(uint32_t)d.ck_pitch / 4;
+    const uint32_t mask = d.ck_mask;
+    for (uint32_t p = lo + blockIdx.x * 256 + threadIdx.x; p < hi; p += gridDim.x * 256) {
+        int q = (int)p;
+        for (int c = c_hi; c >= c_lo; --c) {
+            q -= d.map0[(size_t)c * R + ((uint32_t)q & mask)];
+            q = q < 0 ? 0 : q;
+        }
+        d.map1[(size_t)s * R + (p & mask)] = (uint16_t)((int)p - q);
+    }
+}
+
+// one workgroup per lattice: the end position down the super-chunk maps, then every super-chunk down its chunk maps
+__global__ __launch_bounds__(256) void chain_entries_kernel(const Lattice *__restrict__ lats, const int32_t *meta)
+{
+    const Lattice &d = lats[blockIdx.x];
+    const int32_t *mt = meta + 4 * (size_t)d.idx;
+    if ((mt[2] & (kFlagExact | kFlagDeclined)) || mt[0] != kStatusOk || mt[1] < 0) return;
+    const int T = d.T, nck = chunks_of(T), nsup = supers_of(nck);
+    const size_t R = (size_t)(uint32_t)d.ck_pitch / 4;
+    const uint32_t mask = d.ck_mask;
+    int32_t *entry = d.entry, *entry1 = d.entry + nck;
+    if (threadIdx.x == 0) {
+        int p = mt[1];
+        for (int s = nsup - 1; s >= 0; --s) {
+            entry1[s] = p;
+            if (s > 0) {
+                p -= d.map1[(size_t)s * R + ((uint32_t)p & mask)];
+                p = p < 0 ? 0 : p;
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int s = threadIdx.x; s < nsup; s += blockDim.x) {
+        int p = entry1[s];
+        const int c_hi = min(s * kSuperChunks + kSuperChunks, nck) - 1, c_lo = s * kSuperChunks;
+        for (int c = c_hi; c >= c_lo; --c) {
+            entry[c] = p;
+            if (c > 0) {
+                p -= d.map0[(size_t)c * R + ((uint32_t)p & mask)];
+                p = p < 0 ? 0 : p;
+            }
+        }
+    }
+}
+
+}  // namespace ka

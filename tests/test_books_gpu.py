@@ -17,7 +17,7 @@ from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 
-MODES = ["wave", "workgroup", "wave_exact", "tiled"]
+MODES = ["wave", "workgroup", "wave_exact", "tiled", "wave+parallel", "tiled+parallel", "auto"]
 _oracle_cache = {}
 
 
@@ -55,6 +55,13 @@ def _engine():
     return _lib.default_engine(torch.cuda.current_device())
 
 
+def _set(eng, mode):
+    """'form' or 'form+parallel' (chunk-parallel backtrace forced); 'auto' leaves both choices to the library"""
+    form, _, bt = mode.partition("+")
+    eng.set_mode(form)
+    eng.set_backtrace(bt or ("auto" if form == "auto" else "serial"))
+
+
 def _check_against_oracle(batch, want, idxs=None):
     idxs = range(batch.n) if idxs is None else idxs
     for k, i in enumerate(idxs):
@@ -73,16 +80,16 @@ def test_book_one_launch_every_chapter_vs_oracle(books_on_device, name, mode):
     lps, labs = books_on_device(name)
     want = _oracle(name)
     eng = _engine()
-    eng.set_mode(mode)
+    _set(eng, mode)
     try:
         b = DeviceBatch(lps, labs)
         b.run()
         _check_against_oracle(b, want)
     finally:
-        eng.set_mode("auto")
+        _set(eng, "auto")
 
 
-@pytest.mark.parametrize("mode", ["auto", "tiled"])
+@pytest.mark.parametrize("mode", ["auto", "tiled", "wave+parallel"])
 def test_meian_sharded_over_8_ranks_equals_one_launch(books_on_device, mode):
     """BASELINE configs[3]: the LPT split of sharding.shard_for_rank, every rank's shard as its own launch."""
     from kokoro_align_amd.align import DeviceBatch
@@ -91,7 +98,7 @@ def test_meian_sharded_over_8_ranks_equals_one_launch(books_on_device, mode):
     lps, labs = books_on_device("meian")
     want = _oracle("meian")
     eng = _engine()
-    eng.set_mode(mode)
+    _set(eng, mode)
     try:
         seen = []
         for rank in range(8):
@@ -103,7 +110,7 @@ def test_meian_sharded_over_8_ranks_equals_one_launch(books_on_device, mode):
             seen += mine
         assert sorted(seen) == list(range(len(shapes)))
     finally:
-        eng.set_mode("auto")
+        _set(eng, "auto")
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -116,13 +123,13 @@ def test_cfg1_gongitsune_full_size(mode):
     lps, labs = W.device_book([(c["T"], c["S"])], V=c["V"], seed0=77)
     want = O.lattice_batch_c([(c["T"], c["S"])], c["V"], 77, threads=1)
     eng = _engine()
-    eng.set_mode(mode)
+    _set(eng, mode)
     try:
         b = DeviceBatch(lps, labs)
         b.run()
         _check_against_oracle(b, want)
         assert int(b.path[0][-1]) == 2 * c["S"]
     finally:
-        eng.set_mode("auto")
+        _set(eng, "auto")
     del lps, labs
     torch.cuda.empty_cache()

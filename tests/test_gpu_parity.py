@@ -13,18 +13,23 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["wave", "workgroup", "wave_exact", "tiled"])
+@pytest.fixture(scope="module", params=["wave", "workgroup", "wave_exact", "tiled", "wave+parallel", "tiled+parallel"])
 def ka(request):
     """Every test runs in every kernel form: one wavefront per lattice checkpointed / exact,
-    four wavefronts per lattice, and the tile pipeline.  Results must be identical."""
+    four wavefronts per lattice, the tile pipeline - and the two checkpointed forms once more with the chunk-parallel
+    backtrace forced (the default picks it by batch size).  Results must be identical."""
     import torch
     assert torch.cuda.is_available()
     import kokoro_align_amd as ka
     from kokoro_align_amd import _lib
     assert os.path.exists(ka.library_path()), "HIP library not built"
-    _lib.default_engine(torch.cuda.current_device()).set_mode(request.param)
+    mode, _, bt = request.param.partition("+")
+    eng = _lib.default_engine(torch.cuda.current_device())
+    eng.set_mode(mode)
+    eng.set_backtrace(bt or "serial")
     yield ka
-    _lib.default_engine(torch.cuda.current_device()).set_mode("auto")
+    eng.set_mode("auto")
+    eng.set_backtrace("auto")
 
 
 def _same(got, want):

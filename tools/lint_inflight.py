@@ -14,6 +14,9 @@ reports every v_mov / DPP mov whose SOURCE is a register written by an inline-as
 have landed.  Program order is not execution order across branches, so this is a lint, not a proof: it is
 exact for the straight-line unrolled frame code and for the copies a compiler puts in front of a back-edge.
 
+A third check: an SGPR written by v_readfirstlane / v_readlane and read by a vector-memory instruction less than five
+wait states later (hipcc pads its own code, not asm statements).
+
 A second check covers the other thing hipcc cannot see inside inline asm: a store of more than 64 bits keeps
 reading its data registers for two wait states after it has issued (gfx940+), so the next two instruction slots
 must not write them.  The compiler honours that for its own stores; behind an inline-asm store it happily
@@ -26,7 +29,7 @@ import os
 import re
 import sys
 
-KERNELS = ("forward_ck", "forward_w16", "forward_wg4", "backtrace_rc", "backtrace_w16", "forward_tp")
+KERNELS = ("forward_ck", "forward_w16", "forward_wg4", "backtrace_rc", "backtrace_w16", "forward_tp", "chunk_map")
 VMEM = re.compile(r"\s*(global_load|global_store|buffer_load|buffer_store|flat_load|flat_store|global_atomic)\w*\s+(.*)")
 WAIT = re.compile(r"\s*s_waitcnt\s+(.*)")
 MOV = re.compile(r"\s*v_mov_b32(?:_e32|_dpp|_e64)?\s+(v[0-9]+),\s*(v[0-9]+)\b")
@@ -113,6 +116,32 @@ def check(path):
                     mo = re.match(r"\s*(v_\w+|ds_\w+|global_load\w*|buffer_load\w*)\s+(v\[?[0-9:]+\]?)", nx)
                     if mo and not nx.lstrip().startswith(("v_cmp", "v_cmpx", "ds_write", "ds_bpermute")) and set(regs(mo.group(2))) & set(data):
                         found.append(f"{ln.strip()}  ->  {nx.strip()}")
+                    waited += 1
+                j += 1
+        # an SGPR written by the VECTOR unit (v_readfirstlane / v_readlane) must not be read by a vector-memory
+        # instruction for five wait states; hipcc pads its own instructions, not those inside an asm statement
+        # (seen: a load that used a pointer register's previous contents - the base without the offset)
+        for i, ln in enumerate(lines):
+            mr = re.match(r"\s*v_read(?:first)?lane_b32\s+(s[0-9]+)\b", ln)
+            if not mr:
+                continue
+            sreg = int(mr.group(1)[1:])
+            waited, j = 0, i + 1
+            while waited < 5 and j < len(lines):
+                nx = lines[j]
+                mn = re.match(r"\s*s_nop\s+(\d+)", nx)
+                if mn:
+                    waited += int(mn.group(1)) + 1
+                else:
+                    if VMEM.match(nx):
+                        used = set()
+                        for a, b in re.findall(r"s\[([0-9]+):([0-9]+)\]", nx):
+                            used |= set(range(int(a), int(b) + 1))
+                        used |= {int(x) for x in re.findall(r"\bs([0-9]+)\b", nx)}
+                        if sreg in used:
+                            found.append(f"{ln.strip()}  ->  {nx.strip()}  ({waited} wait states)")
+                    if re.match(r"\s*(s_|v_)\w+\s+s\[?%d\b" % sreg, nx) or re.match(r"\s*s_\w+\s+s\[%d:" % sreg, nx):
+                        break      # the register is rewritten
                     waited += 1
                 j += 1
         report.append((m.group(1), found))
