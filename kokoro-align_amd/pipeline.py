@@ -8,6 +8,7 @@ Reference stages mirrored (run_example.py:146-280 `process`, stages 4-7):
   align          kokoro_align/align.py:127-169   -> *.align.txt
   combine_files  run_example.py:73-131           *.align.txt + *.split.txt -> <id>.metadata.txt
 Every stage is skipped when its output exists (run_example.py:227-228, :249-250, :262-263, :274-275).
+process_alignment_sharded runs a dataset over the ranks of a node (one process per GPU, files split by work).
 Upstream stages (Aozora text, G2P, MP3 split + MFCC) are not part of this package.
 """
 import os
@@ -23,24 +24,26 @@ from .encoder import decode_text, encode_text, is_valid_text, merge_repeated
 # (int32), `data` = all segments concatenated along axis 0
 # ------------------------------------------------------------------------------------------
 class IndexDataArray:
+    """Writer of the segmented-array npz the reference's stages exchange (kokoro_align/preprocess.py:12-35): segments are
+    appended with write(); on a clean exit of the ``with`` block ONE npz is written with `indices` (int32, cumulative
+    row count after every segment) and `data` (all segments stacked on axis 0); after an exception nothing is written."""
+
     def __init__(self, file):
         self.file = file
-        self.current = 0
-        self.indices = []
-        self.data = []
+        self._segments = []
 
     def __enter__(self):
         return self
 
-    def write(self, data):
-        self.current += data.shape[0]
-        self.indices.append(self.current)
-        self.data.append(data)
+    def write(self, segment):
+        self._segments.append(np.asarray(segment))
 
     def __exit__(self, exc_type, exc_value, traceback):
-        if exc_type is None:   # nothing is written when the producer failed (preprocess.py:27-31)
-            np.savez(self.file, indices=np.array(self.indices, dtype=np.int32),
-                     data=np.concatenate(self.data, axis=0))
+        if exc_type is not None:
+            return False
+        ends = np.cumsum([seg.shape[0] for seg in self._segments], dtype=np.int64).astype(np.int32)
+        np.savez(self.file, indices=ends, data=np.concatenate(self._segments, axis=0))
+        return False
 
 
 def open_index_data_for_write(file):
@@ -242,8 +245,54 @@ def _swap_ext(files, old, new):
     return [f[:-len(old)] + new if f.endswith(old) else f for f in files]
 
 
+def process_alignment_sharded(dataset, audio_files, metadata_file, model=None, remove_wordsep=False, device=None,
+                              host_softmax=False, verbose=True, rank=None, world_size=None, barrier=None,
+                              best_path_files_fn=None):
+    """process_alignment for one dataset over the ranks of a node: one process per GPU (torch.distributed, RCCL);
+    BASELINE.json configs[3] ("Meian sharded across 8 GPUs").
+
+    The reference loops the files of a dataset one after the other (run_example.py:224-267) and they share nothing, so
+    the files are split over the ranks - longest-processing-time first on the work T x min(beam, 2S+1) of their
+    lattices (sharding.shard_for_rank; T from the `*.mfcc.npz` indices, S from the `*.voca.txt`) - and every rank runs
+    predict -> best_path -> align for ITS files in one batched launch and writes their per-file outputs, exactly the
+    files the reference would write.  No collective touches the data path; after a barrier rank 0 joins all
+    `*.align.txt` into the metadata file (run_example.py:273-278).  The model is assumed to be on every rank already
+    (sharding.broadcast_model_weights at start-up).  `rank` / `world_size` / `barrier` default to torch.distributed's;
+    `best_path_files_fn` replaces the DP stage (the CPU tests put the oracle there: the product has no CPU path).
+    Returns the metadata file name on rank 0, None elsewhere."""
+    from .sharding import shard_for_rank
+    from .transcript import read_transcript
+    if rank is None or world_size is None:
+        import torch.distributed as dist
+        rank, world_size = dist.get_rank(), dist.get_world_size()
+        if barrier is None:
+            barrier = dist.barrier
+    shapes = []
+    for af in audio_files:
+        mf, vf = _swap_ext([af], '.mp3', '.mfcc.npz')[0], _swap_ext([af], '.mp3', '.voca.txt')[0]
+        with np.load(mf) as f:
+            ends = f['indices']
+        shapes.append((int(ends[-1]) if len(ends) else 0, int(len(read_transcript(vf)))))
+    mine = [audio_files[i] for i in shard_for_rank(shapes, rank, world_size)]
+    if mine:
+        process_alignment(dataset, mine, None, model=model, remove_wordsep=remove_wordsep, device=device,
+                          host_softmax=host_softmax, verbose=verbose, best_path_files_fn=best_path_files_fn)
+    if barrier is not None:
+        barrier()
+    if rank != 0:
+        return None
+    say = print if verbose else (lambda *a, **k: None)
+    if os.path.exists(metadata_file):
+        say(f'Skip writing {metadata_file}')
+    else:
+        say(f'Writing {metadata_file}')
+        combine_files(dataset, _swap_ext(audio_files, '.mp3', '.align.txt'), audio_files,
+                      _swap_ext(audio_files, '.mp3', '.split.txt'), metadata_file, remove_wordsep, verbose=verbose)
+    return metadata_file
+
+
 def process_alignment(dataset, audio_files, metadata_file, model=None, remove_wordsep=False, device=None,
-                      host_softmax=False, verbose=True):
+                      host_softmax=False, verbose=True, best_path_files_fn=None):
     """Given `<x>.mp3` names whose `<x>.voca.txt` exist (made by the reference's upstream stages), run
     split_audio -> predict -> best_path -> align -> combine_files with skip-if-exists (run_example.py:205-275),
     all lattices of the dataset in one DP launch.  The split_audio stage (run_example.py:205-218) runs where
@@ -285,7 +334,8 @@ def process_alignment(dataset, audio_files, metadata_file, model=None, remove_wo
         else:
             for mf, lf, gf in missing:
                 on_device[lf] = predict(model, mf, lf, gf, device=dev)
-    written = best_path_files(logits, voca, bpath, device=device, logits_on_device=on_device, host_softmax=host_softmax)
+    written = (best_path_files_fn or best_path_files)(logits, voca, bpath, device=device, logits_on_device=on_device,
+                                                       host_softmax=host_softmax)
     for bf in bpath:
         say(f'Writing {bf}' if bf in written else f'Skip writing {bf}')
     for bf, mf, vf, af in zip(bpath, mfcc, voca, align_out):
@@ -294,6 +344,8 @@ def process_alignment(dataset, audio_files, metadata_file, model=None, remove_wo
         else:
             say(f'Writing {af}')
             _write_align(bf, mf, vf, af, remove_wordsep=remove_wordsep)
+    if metadata_file is None:      # a rank's share of a dataset (process_alignment_sharded): rank 0 writes the metadata
+        return None
     if os.path.exists(metadata_file):
         say(f'Skip writing {metadata_file}')
     else:

@@ -61,14 +61,16 @@ def _dct_ortho(n_mfcc, n_mels):
 # silence splitting
 # ----------------------------------------------------------------------------------------
 def get_silent_ranges(voiced):
-    """kokoro_align/preprocess.py:38-48."""
-    silent_to_voiced = np.where((~voiced[:-1]) & voiced[1:])[0] + 1
-    voiced_to_silent = np.where((voiced[:-1]) & ~voiced[1:])[0] + 1
-    if not voiced[0]:
-        silent_to_voiced = silent_to_voiced[1:]    # drop the leading silence
-    if not voiced[-1]:
-        voiced_to_silent = voiced_to_silent[:-1]   # drop the trailing silence
-    return np.stack([voiced_to_silent, silent_to_voiced]).T
+    """[[start, end)] of every run of silent windows that has voiced windows on BOTH sides (int array [n, 2]); a
+    silence the recording begins or ends with is not a place to split (kokoro_align/preprocess.py:38-48)."""
+    v = np.asarray(voiced, dtype=bool)
+    change = np.flatnonzero(v[1:] != v[:-1]) + 1          # window indices at which voiced/silent flips
+    falls = change[~v[change]]                             # ... into silence
+    rises = change[v[change]]                              # ... back into voice
+    if len(rises) and (len(falls) == 0 or rises[0] < falls[0]):
+        rises = rises[1:]                                  # the recording began silent: that rise closes no inner silence
+    n = min(len(falls), len(rises))                        # a silence that runs to the end has no rise
+    return np.stack([falls[:n], rises[:n]], axis=1)
 
 
 def window_energy(x, window_size, device=None):
@@ -90,31 +92,38 @@ def window_energy(x, window_size, device=None):
 
 def get_split_points(x, minimum_silent_frames, minimum_split_distance, maximum_split_distance, window_size, eps=1e-12,
                      device=None):
-    """kokoro_align/preprocess.py:51-97: split points, in windows."""
-    mX = window_energy(x, window_size, device=device)
-    num_frames = len(mX)
-    mX = 10 * np.log(mX + eps)
-    silent_threshold = (np.max(mX) + np.min(mX)) / 2
+    """Where to cut a recording, in windows of ``window_size`` samples (kokoro_align/preprocess.py:51-97).
+
+    A window is voiced when its level, 10 ln(mean square + eps), lies above the midpoint between the loudest and the
+    quietest window.  Silences shorter than ``minimum_silent_frames`` windows are filled in, every remaining inner
+    silence gives one cut at its centre; while some piece is still ``maximum_split_distance`` windows or longer the
+    minimum silence is halved and the search repeated (ValueError below 0.05 windows).  Pieces not longer than
+    ``minimum_split_distance`` are then merged into a neighbour."""
+    level = window_energy(x, window_size, device=device)
+    n_windows = len(level)
+    level = 10 * np.log(level + eps)
+    threshold = (np.max(level) + np.min(level)) / 2
     while True:
-        voiced = mX > silent_threshold
-        # fill short silences (preprocess.py:63-65 does it range by range; the ranges are disjoint, so marking
-        # starts +1 / ends -1 and taking the running sum fills them all at once: a recording of 8 hours has
-        # ~10^4 ranges and this loop runs up to 9 times)
-        r = get_silent_ranges(voiced)
-        short = (r[:, 1] - r[:, 0]) < minimum_silent_frames
+        voiced = level > threshold
+        # fill the short silences.  The ranges are disjoint, so +1 at every start, -1 at every end and a running sum
+        # fill them all at once (the reference fills range by range; 8 hours of audio have ~10^4 of them and this
+        # loop runs up to 9 times)
+        ranges = get_silent_ranges(voiced)
+        short = (ranges[:, 1] - ranges[:, 0]) < minimum_silent_frames
         if short.any():
-            mark = np.zeros(num_frames + 1, dtype=np.int32)
-            mark[r[short, 0]] = 1
-            mark[r[short, 1]] -= 1
-            voiced |= np.cumsum(mark[:-1]) > 0
-        silent_ranges = get_silent_ranges(voiced)
-        silent_points = (silent_ranges[:, 0] + silent_ranges[:, 1]) // 2   # split in the centre of a silence
-        split_distance = np.append(silent_points, num_frames) - np.insert(silent_points, 0, 0)
-        if np.max(split_distance) < maximum_split_distance:
+            step = np.zeros(n_windows + 1, dtype=np.int32)
+            step[ranges[short, 0]] = 1
+            step[ranges[short, 1]] -= 1
+            voiced |= np.cumsum(step[:-1]) > 0
+        ranges = get_silent_ranges(voiced)
+        silent_points = (ranges[:, 0] + ranges[:, 1]) // 2
+        pieces = np.diff(np.concatenate(([0], silent_points, [n_windows])))
+        if np.max(pieces) < maximum_split_distance:
             break
         minimum_silent_frames *= 0.5
         if minimum_silent_frames < 0.05:
             raise ValueError("Audio cannot be split into")
+    num_frames = n_windows
     return _merge_short_pieces(silent_points, num_frames, minimum_split_distance)
 
 

@@ -26,45 +26,48 @@ def read_transcript(input_file):
 
 
 class VocaAligner:
-    """token_pos[p] = token index at which a cut falling on phoneme p is placed
-    (transcript.py:14-42): phonemes up to a token's midpoint cut before it (swallowing
-    preceding tokens without phonemes unless they are punctuation), later ones after it."""
+    """Where to cut the text when the audio is cut at a given phoneme.
+
+    ``token_pos[p]`` is the index of the token in front of which the text is cut when the cut in the audio falls on
+    phoneme ``p`` of the transcript (all tokens' phonemes counted through).  Rule of the reference
+    (transcript.py:14-42): the phonemes of a token up to its midpoint - ``len - len // 2`` of them - send the cut
+    to where it stood before the token, the rest send it behind the token; tokens without phonemes (``「``, a
+    geminate ``q``, ...) are carried along by the next cut, except punctuation (`` , . ! ? ``), which pulls the cut
+    behind itself.  ``len(aligner)`` is the number of phonemes that have a cut position."""
 
     def __init__(self, input_file):
-        self.text_tokens = []
-        self.voca_tokens = []
-        self.attach_dirs = []
+        self._texts, self._vocas = [], []
         self.token_pos = []
-        n_tokens = 0      # tokens seen so far
-        n_phonemes = 0    # phonemes seen so far
-        cut = 0           # token index a cut is currently placed at
+        phonemes_seen = 0
+        cut_at = 0
         for text, voca in _read_pairs(input_file):
-            n = len(encode_text(voca))
-            self.text_tokens.append(text)
-            self.voca_tokens.append(voca)
-            n_tokens += 1
-            if n > 0:
-                n_phonemes += n
-                upto = n_phonemes - n // 2
-                self.token_pos.extend([cut] * (upto - len(self.token_pos)))
-                cut = n_tokens
+            self._texts.append(text)
+            self._vocas.append(voca)
+            here = len(self._texts)              # a cut behind this token
+            count = len(encode_text(voca))
+            if count:
+                phonemes_seen += count
+                first_half_end = phonemes_seen - count // 2
+                self.token_pos += [cut_at] * (first_half_end - len(self.token_pos))
+                cut_at = here
             elif voca in _PUNCT:
-                cut = n_tokens
+                cut_at = here
 
     def __len__(self):
         return len(self.token_pos)
 
+    def _cut(self, phoneme):
+        return self.token_pos[phoneme] if phoneme < len(self.token_pos) else len(self._texts)
+
     def get_token(self, start, end, remove_wordsep=True):
-        """Text and phonemes of the tokens between two phoneme indices (transcript.py:47-57)."""
-        n = len(self.token_pos)
-        first = self.token_pos[start] if start < n else len(self.text_tokens)
-        last = self.token_pos[end] if end < n else len(self.text_tokens)
-        text = ' '.join(tok for tok in self.text_tokens[first:last] if tok)
-        vocas = [tok for tok in self.voca_tokens[first:last] if tok]
+        """(text, phonemes) of the tokens between the cuts of two phoneme indices (transcript.py:47-57); with
+        ``remove_wordsep=False`` the tokens' phonemes are joined with the word separator `` _ ``, which is dropped next
+        to punctuation."""
+        a, b = self._cut(start), self._cut(end)
+        text = ' '.join(t for t in self._texts[a:b] if t)
+        vocas = [v for v in self._vocas[a:b] if v]
         if remove_wordsep:
             voca = ' '.join(vocas)
         else:
-            voca = ' _ '.join(vocas)
-            voca = _SEP_BEFORE_PUNCT.sub(r'\1', voca)
-            voca = _SEP_AFTER_PUNCT.sub(r'\1', voca)
+            voca = _SEP_AFTER_PUNCT.sub(r'\1', _SEP_BEFORE_PUNCT.sub(r'\1', ' _ '.join(vocas)))
         return text.strip(), voca.strip()
