@@ -30,7 +30,7 @@ namespace ka {
 constexpr int kTpCells = 4;                    // cells per lane
 constexpr int kTpTile = 64 * kTpCells;         // positions per tile
 constexpr int kTpBlock = 16;                   // frames per staging block
-constexpr int kTpRing = 3;                     // LDS staging slots (block k reads slot k % 3, block k+1 is being written)
+constexpr int kTpRing = 4;                     // LDS staging slots: the block being computed, the next one (landed), two more in flight
 constexpr int kTpRowBytes = 256;               // LDS pitch of a staged row (64 columns)
 constexpr uint32_t kTpSentinel = 0x7fc0deadu;  // verification fill of the halo region (a NaN: no score is ever NaN)
 constexpr uint32_t kTpProgDone = 0x7fffffffu;  // progress word of a finished tile / of "no tile below"
@@ -146,11 +146,13 @@ __device__ __forceinline__ void tp_prog_load(uint32_t &dst, gu32w_t word /* unif
 struct TpStats {
     unsigned long long wait_ticks, total_ticks, spins, start_tick;   // 100 MHz ticks (KA_TP_VERIFY & 4: ka_debug_tile_stats)
 };
-__device__ __forceinline__ bool tp_wait_progress(gu32w_t word, uint32_t need, uint32_t want, uint32_t have, TpStats &st)
+// (diagnostic counters - number of waits, 100 MHz ticks spent in them - live in two LDS words at `stat_lds`)
+__device__ __forceinline__ bool tp_wait_progress(gu32w_t word, uint32_t need, uint32_t want, uint32_t have, uint32_t stat_lds)
 {
     if (have >= need) return true;
     const uint64_t t0 = wall_clock64();   // 100 MHz
-    ++st.spins;
+    __attribute__((address_space(3))) uint32_t *st = (__attribute__((address_space(3))) uint32_t *)(uintptr_t)stat_lds;
+    st[0] += 1;
     for (;;) {
         const uint32_t gap = want - have;
         if (gap > 4096u) __builtin_amdgcn_s_sleep(127);
@@ -162,7 +164,7 @@ __device__ __forceinline__ bool tp_wait_progress(gu32w_t word, uint32_t need, ui
         have = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
         const uint64_t waited = wall_clock64() - t0;
         if (have >= want) {
-            st.wait_ticks += waited;
+            st[1] += (uint32_t)waited;
             return true;
         }
         if (waited > 400000000ull) return false;
@@ -172,7 +174,8 @@ __device__ __forceinline__ bool tp_wait_progress(gu32w_t word, uint32_t need, ui
 template <int M, bool ZL>
 struct TpTile {
     // wave-uniform description of the tile and its lattice
-    uint32_t T, L, B, halfB, dq, dr, thr_real;
+    uint32_t T, L, B, dq, dr;   // (B/2 and the band-step threshold are derived where they are needed: scalar registers are scarce here)
+    __device__ __forceinline__ uint32_t thr_real() const { return dq != 0 ? 0u : T; }
     int32_t base, t_in, t_end;
     const char *lp;
     size_t ld;
@@ -182,7 +185,7 @@ struct TpTile {
     const char *out_block;  // slot 16 kb of the block being computed (frame 16 kb + f publishes slot f + 1 of it)
     gu32w_t prog_in, prog_out;
     char *ck;               // checkpoint k (scores after frame 32 (k + 1) - 1) at ck + k * ck_pitch
-    size_t ck_pitch;
+    uint32_t ck_pitch;
     uint32_t ck_off;        // per lane: ((base + 4 lane) & ck_mask) * 4
     // band state of the frame being computed
     uint32_t q, rem, lo, hi, thr;
@@ -195,6 +198,7 @@ struct TpTile {
     float absum;
     // LDS
     uint32_t lds_rows, lds_halo;   // byte addresses of this workgroup's staging rings
+    uint32_t lds_stage;            // per lane: byte address of its 16 bytes in frame 0's row of the publish staging area
 };
 
 // One frame, F = its index in the block.  The LDS reads run TWO frames ahead of their use (an LDS read takes longer than
@@ -209,14 +213,26 @@ struct TpIn {
 };
 template <int M, bool ZL, bool GUARDED, int F>
 __device__ __forceinline__ void tp_frame(TpTile<M, ZL> &c, uint32_t t, float (&H)[3], TpIn &cur, TpIn &nxt, uint32_t r2_l0, uint32_t r2_l1, uint32_t r2_0,
-                                         uint32_t h2, uint64_t lane63, float NINF)
+                                         uint32_t h2, float NINF)
 {
     const bool live = !GUARDED || ((int32_t)t >= c.t_in && (int32_t)t < c.t_end);
     // LDS reads of frame t+2 (skipped frames read too: they prime the pipeline)
     TpIn far;
+#if defined(KA_TP_EXP) && KA_TP_EXP == 3   // timing experiment only (results wrong): no LDS reads in the frame
+    far.E = f32x2{-1.0f, -2.0f};
+    far.e0 = -1.5f;
+    far.hp = f32x4{NINF, NINF, NINF, NINF};
+    (void)r2_l0; (void)r2_l1; (void)r2_0; (void)h2;
+#elif defined(KA_TP_EXP) && KA_TP_EXP == 4   // timing experiment only: emissions read, the packet not
+    far.E = f32x2{lds_f32(r2_l0), lds_f32(r2_l1)};
+    far.e0 = lds_f32(r2_0);
+    far.hp = f32x4{NINF, NINF, NINF, NINF};
+    (void)h2;
+#else
     far.E = f32x2{lds_f32(r2_l0), lds_f32(r2_l1)};
     far.e0 = lds_f32(r2_0);
     far.hp = lds_f32x4(h2);
+#endif
     if (live) {
         const float b0 = c.S[0], b1 = c.S[1], l0 = c.S[2], l1 = c.S[3];
         f32x2 ml, mb;
@@ -232,29 +248,26 @@ __device__ __forceinline__ void tp_frame(TpTile<M, ZL> &c, uint32_t t, float (&H
         c.rem += c.dr;
         if (__builtin_expect(c.rem >= c.thr, 0)) {
             asm volatile("" ::: "memory");
-            c.thr = c.thr_real;
+            c.thr = c.thr_real();
             if (c.edge) tp_mask_state(c.S, c.mk, NINF);
-            if (c.rem >= c.thr_real) {
+            if (c.rem >= c.thr_real()) {
                 c.q += c.dq;
                 if (c.rem >= c.T) { c.rem -= c.T; ++c.q; }
                 if (t + 1 != c.T) {
-                    const int32_t dlo = (int32_t)c.q - (int32_t)c.halfB;
+                    const int32_t dlo = (int32_t)c.q - (int32_t)(c.B >> 1);
                     const uint32_t nlo = (uint32_t)(dlo > 0 ? dlo : 0);
                     const uint32_t nhi = (c.L - nlo < c.B) ? c.L : nlo + c.B;
                     if (nlo != c.lo || nhi != c.hi) {
+                        // the masks follow the band position by position (usually one leaves, one enters; only those
+                        // inside the tile cost anything) - kept up to date always, so there is no rebuild path here
+                        const uint32_t tile_lo = (uint32_t)c.base, tile_hi = (uint32_t)c.base + kTpTile;
+                        for (uint32_t p = c.lo > tile_lo ? c.lo : tile_lo; p < (nlo < tile_hi ? nlo : tile_hi); ++p) tp_mask_toggle(c.mk, (int32_t)(p - tile_lo));
+                        for (uint32_t p = c.hi > tile_lo ? c.hi : tile_lo; p < (nhi < tile_hi ? nhi : tile_hi); ++p) tp_mask_toggle(c.mk, (int32_t)(p - tile_lo));
                         const bool was_edge = c.edge;
-                        c.edge = (int32_t)nlo > c.base || (int32_t)nhi < c.base + kTpTile;
-                        if (c.edge) {   // (the masks are kept up to date only while an edge is inside the tile)
-                            if (was_edge && nlo - c.lo <= 1u && nhi - c.hi <= 1u) {   // the usual step: one position leaves, one enters
-                                if (nlo != c.lo) tp_mask_toggle(c.mk, (int32_t)c.lo - c.base);
-                                if (nhi != c.hi) tp_mask_toggle(c.mk, (int32_t)c.hi - c.base);
-                            } else {
-                                tp_masks(c.mk, (int32_t)nlo - c.base, (int32_t)nhi - c.base);
-                            }
-                        }
-                        if (c.edge || was_edge) c.thr = 0;   // frame t+1 is the first of a new band: it must come through here again (rule ii)
                         c.lo = nlo;
                         c.hi = nhi;
+                        c.edge = nlo > tile_lo || nhi < tile_hi;
+                        if (c.edge || was_edge) c.thr = 0;   // frame t+1 is the first of a new band: it must come through here again (rule ii)
                     }
                 }
             }
@@ -268,7 +281,11 @@ __device__ __forceinline__ void tp_frame(TpTile<M, ZL> &c, uint32_t t, float (&H
     H[1] = wave_shr1(nxt.hp[1], c.S[1]);   // - 2 (blank)
     H[2] = wave_shr1(nxt.hp[2], c.S[2]);   // - 3 (label)
     // publish the state after frame t = slot t+1 of the upper boundary (lane 63's four cells)
-    if (live) tp_halo_store<(F + 1) * 16>(c.out_block, c.S, lane63);
+    // (staged: every lane drops its four cells into this frame's 1-KB row of the LDS staging area - no EXEC change and
+    //  no vector-memory instruction per frame; lane 63's go out at the end of the block, tp_publish_block)
+#if !(defined(KA_TP_EXP) && KA_TP_EXP == 5)   // (5: timing experiment only, nothing staged)
+    if (live) *(__attribute__((address_space(3))) f32x4 *)(uintptr_t)(c.lds_stage + F * 1024) = c.S;
+#endif
     cur = nxt;
     nxt = far;
 }
@@ -279,20 +296,32 @@ struct TpAddr {
     uint32_t l0, l1, r, h;
 };
 template <int M, bool ZL, bool GUARDED, int F>
-__device__ __forceinline__ void tp_block_frames(TpTile<M, ZL> &c, uint32_t tb, float (&H)[3], TpIn &cur, TpIn &nxt, const TpAddr (&A)[2], uint64_t lane63, float NINF)
+__device__ __forceinline__ void tp_block_frames(TpTile<M, ZL> &c, uint32_t tb, float (&H)[3], TpIn &cur, TpIn &nxt, const TpAddr (&A)[2], float NINF)
 {
     // frame t+2 = F+2 of this block, or F+2-16 of the next one
     constexpr int F2 = (F + 2) % kTpBlock, W = (F + 2) / kTpBlock;
     tp_frame<M, ZL, GUARDED, F>(c, tb + F, H, cur, nxt, A[W].l0 + F2 * kTpRowBytes, A[W].l1 + F2 * kTpRowBytes, A[W].r + F2 * kTpRowBytes, A[W].h + F2 * 16,
-                                lane63, NINF);
-    if constexpr (F + 1 < kTpBlock) tp_block_frames<M, ZL, GUARDED, F + 1>(c, tb, H, cur, nxt, A, lane63, NINF);
+                                NINF);
+    if constexpr (F + 1 < kTpBlock) tp_block_frames<M, ZL, GUARDED, F + 1>(c, tb, H, cur, nxt, A, NINF);
+}
+
+// end of a block: lane f < 16 fetches what lane 63 staged in frame f and stores it as slot tb + f + 1 (one write-through
+// store instruction for the block's 16 packets = 256 contiguous bytes); frames the tile did not compute store nothing
+template <int M, bool ZL>
+__device__ __forceinline__ void tp_publish_block(TpTile<M, ZL> &c, uint32_t tb, int lane)
+{
+    const int32_t t = (int32_t)tb + lane;
+    if (lane < kTpBlock && t >= c.t_in && t < c.t_end) {
+        const f32x4 pk = lds_f32x4(c.lds_stage - (uint32_t)lane * 16u + (uint32_t)lane * 1024u + 63u * 16u);
+        asm volatile("global_store_dwordx4 %0, %1, %2 offset:16 sc1\n\ts_nop 1" : : "v"((uint32_t)lane * 16u), "v"(pk), "s"(c.out_block) : "memory");
+    }
 }
 
 template <int M, bool ZL>
 __device__ __forceinline__ void tp_checkpoint(TpTile<M, ZL> &c, uint32_t t_next /* multiple of 32 */)
 {
     const f32x4 v = {c.S[0], c.S[2], c.S[1], c.S[3]};   // cells 0..3 in position order
-    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(c.ck_off), "v"(v), "s"(c.ck + ((size_t)(t_next / kCkFrames) - 1) * c.ck_pitch) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(c.ck_off), "v"(v), "s"(c.ck + ((size_t)(t_next / kCkFrames) - 1) * (size_t)c.ck_pitch) : "memory");
 }
 
 // ---------------------------------------------------------------------------------------
@@ -302,18 +331,20 @@ template <int M, bool ZL>
 __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk, int32_t *meta, char *halo, gu32w_t prog, TileAux *aux,
                                             uint32_t lds_rows, uint32_t lds_halo, int verify, TpStats *stats_out)
 {
-    TpStats st = {0, 0, 0, (unsigned long long)wall_clock64()};
+    const uint32_t stat_lds = lds_halo + kTpRing * kTpBlock * 16 + 16 + kTpBlock * 1024;   // diagnostic words behind the staging areas
+    if (threadIdx.x < 3) ((__attribute__((address_space(3))) uint32_t *)(uintptr_t)stat_lds)[threadIdx.x] = 0;
+    if (verify & 4) {   // start stamps: wall clock (100 MHz) and shader clock
+        stats_out->start_tick = (unsigned long long)wall_clock64();
+        stats_out->total_ticks = __builtin_amdgcn_s_memtime();
+    }
     const int lane = threadIdx.x;
     const float NINF = ninf();
-    const uint64_t lane63 = 1ull << 63;
     TpTile<M, ZL> c;
     c.T = (uint32_t)__builtin_amdgcn_readfirstlane(d.T);
     c.L = (uint32_t)__builtin_amdgcn_readfirstlane(d.L);
     c.B = (uint32_t)__builtin_amdgcn_readfirstlane(d.beam);
-    c.halfB = c.B >> 1;
     c.dq = c.L / c.T;
     c.dr = c.L % c.T;
-    c.thr_real = c.dq != 0 ? 0u : c.T;
     c.base = __builtin_amdgcn_readfirstlane(tk.tile) * kTpTile;
     c.t_in = __builtin_amdgcn_readfirstlane(tk.t_in);
     c.t_end = __builtin_amdgcn_readfirstlane(tk.t_end);
@@ -325,21 +356,22 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
     c.prog_in = prog + tk.prog_in;
     c.prog_out = prog + tk.prog_out;
     c.ck = reinterpret_cast<char *>(d.bp);
-    c.ck_pitch = (size_t)(uint32_t)d.ck_pitch;
+    c.ck_pitch = (uint32_t)d.ck_pitch;
     c.ck_off = (((uint32_t)c.base + 4u * (uint32_t)lane) & (uint32_t)d.ck_mask) * 4u;
     c.lds_rows = lds_rows;
     c.lds_halo = lds_halo;
+    c.lds_stage = lds_halo + kTpRing * kTpBlock * 16 + 16 + (uint32_t)lane * 16u;   // (16 bytes of progress looks sit in between)
     // band of frame t_in (64-bit division once per tile; wave-uniform)
     {
         const uint64_t x = (uint64_t)c.L * (uint64_t)(uint32_t)c.t_in;
         c.q = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x / c.T));
         c.rem = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x % c.T));
-        const int32_t dlo = (int32_t)c.q - (int32_t)c.halfB;
+        const int32_t dlo = (int32_t)c.q - (int32_t)(c.B >> 1);
         c.lo = (uint32_t)(dlo > 0 ? dlo : 0);
         c.hi = (c.L - c.lo < c.B) ? c.L : c.lo + c.B;
         c.edge = (int32_t)c.lo > c.base || (int32_t)c.hi < c.base + kTpTile;
         tp_masks(c.mk, (int32_t)c.lo - c.base, (int32_t)c.hi - c.base);
-        c.thr = c.thr_real;
+        c.thr = c.thr_real();
         asm("" : "+s"(c.thr));
     }
     // labels of the lane's two label cells (positions base + 4 lane + 1, + 3); labx is zero padded past S
@@ -354,115 +386,110 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
     c.S = f32x4{NINF, NINF, NINF, NINF};
     if (c.base == 0 && c.t_in == 0 && lane == 0) c.S[0] = 0.0f;
     c.absum = 0.0f;
-    tp_halo_store<0>(c.halo_out, c.S, lane63);   // slot t_in: the state before the tile's first frame
+    tp_halo_store<0>(c.halo_out, c.S, 1ull << 63);   // slot t_in: the state before the tile's first frame
 
-    // ---- staging: block k = frames [16 k, 16 k + 16); rows and halo packets of a block are loaded together ----
-    float rows[kTpBlock];
-    f32x4 hreg = {NINF, NINF, NINF, NINF};
-    uint32_t pv = 0;   // polled progress of the tile below
+    // ---- staging: block k = frames [16 k, 16 k + 16).  A block's 16 log-prob rows, its 16 halo packets and a look at the
+    // progress word of the tile below are fetched by LDS-DMA (global_load_lds: memory -> LDS, no register in between)
+    // THREE iterations before the block is computed and are waited for one iteration before: two blocks of latency
+    // cover (a block of frames is ~0.7 us of work, a row from HBM ~0.4-1 us away, a write-through packet further),
+    // four LDS slots.  Nothing in flight lives in a register, so none of the hazards of asm loads applies here.
+    typedef __attribute__((address_space(1))) const void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    typedef __attribute__((address_space(3))) char *lchar_t;
     const uint32_t last_row = c.T - 1;
     const uint32_t last_slot = (uint32_t)c.t_end - 1;     // this tile reads slots t_in .. t_end - 1
-    uint32_t issued_tb = 0;
-    auto issue_block = [&](uint32_t tb) {
-        issued_tb = tb;
-        // ONE path (see land_block): a running row pointer that stops at the lattice's last row
-        const char *rp = c.lp + (size_t)(tb < last_row ? tb : last_row) * c.ld;
+    const uint32_t lds_poll = c.lds_halo + kTpRing * kTpBlock * 16;
+    auto ring = [](int32_t k) { return (uint32_t)((k % kTpRing + kTpRing) % kTpRing); };
+    auto issue_block = [&](int32_t k) {    // k >= 0
+        const uint32_t tb = (uint32_t)k * kTpBlock, slot = ring(k);
+        const char *rp = c.lp + (size_t)(tb < last_row ? tb : last_row) * c.ld;   // wave-uniform; the lane's column is a 32-bit offset
+        lchar_t dst = (lchar_t)(uintptr_t)(c.lds_rows + slot * (kTpBlock * kTpRowBytes));
+        if (tb + kTpBlock <= c.T) {      // every row of the block exists (nothing in flight lives in a register: two paths are fine here)
 #pragma unroll
-        for (int f = 0; f < kTpBlock; ++f) {
-            row_reload(rows[f], c.lane_off, rp);
-            rp += tb + f < last_row ? c.ld : 0;
+            for (int f = 0; f < kTpBlock; ++f) {
+                __builtin_amdgcn_global_load_lds((gptr_t)(rp + c.lane_off), (lptr_t)(dst + f * kTpRowBytes), 4, 0, 0);   // row tb+f: lane = column, 256 B
+                rp += c.ld;
+            }
+        } else {                         // the lattice's last rows, and blocks requested past them: stop at row T-1
+#pragma unroll
+            for (int f = 0; f < kTpBlock; ++f) {
+                __builtin_amdgcn_global_load_lds((gptr_t)(rp + c.lane_off), (lptr_t)(dst + f * kTpRowBytes), 4, 0, 0);
+                rp += tb + f < last_row ? c.ld : 0;
+            }
         }
-        {
-            uint32_t s = tb + (uint32_t)(lane & (kTpBlock - 1));
+        if (lane < kTpBlock) {       // slots tb .. tb+15 of the lower boundary (clamped to what exists): 16 lanes x 16 B, write-through data: sc1
+            uint32_t s = tb + (uint32_t)lane;
             s = s < (uint32_t)c.t_in ? (uint32_t)c.t_in : (s > last_slot ? last_slot : s);
-            const uint32_t off = (s - (uint32_t)c.t_in) * 16u;
-            asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "+v"(hreg) : "v"(off), "s"(c.halo_in) : "memory");
+            __builtin_amdgcn_global_load_lds((gptr_t)(c.halo_in + (size_t)(s - (uint32_t)c.t_in) * 16), (lptr_t)(lchar_t)(uintptr_t)(c.lds_halo + slot * (kTpBlock * 16)), 16, 0, 16);
         }
-        tp_prog_load(pv, c.prog_in);
+        if (lane == 0) __builtin_amdgcn_global_load_lds((gptr_t)c.prog_in, (lptr_t)(lchar_t)(uintptr_t)(lds_poll + slot * 4), 4, 0, 16);
     };
-    // Block landed -> LDS.  `younger` = vector-memory operations issued since the block's loads (halo stores, a
-    // checkpoint): the wait may leave exactly that many in flight, and N must never EXCEED the true count (vmcnt is
-    // an in-order counter: with N larger than the number of younger operations the loads themselves may be among the N).
-    uint32_t landing_tb = 0;   // first frame of the block whose loads are in flight (verification only)
+    constexpr int kIssued = kTpBlock + 2;   // vector-memory instructions of one issue_block
+    // everything issued by the issue_block of TWO iterations ago has landed once at most `younger` younger operations
+    // are in flight (vmcnt is an in-order counter; never pass more than were really issued since)
+    auto wait_landed = [&](uint32_t younger) {
+        asm volatile("s_cmp_ge_u32 %0, %1+4\n\ts_cbranch_scc1 .Lka_w4_%=\n\t"
+                     "s_cmp_ge_u32 %0, %1+3\n\ts_cbranch_scc1 .Lka_w3_%=\n\t"
+                     "s_cmp_ge_u32 %0, %1+2\n\ts_cbranch_scc1 .Lka_w2_%=\n\t"
+                     "s_cmp_ge_u32 %0, %1+1\n\ts_cbranch_scc1 .Lka_w1_%=\n\t"
+                     "s_cmp_ge_u32 %0, %1\n\ts_cbranch_scc1 .Lka_w0_%=\n\t"
+                     "s_waitcnt vmcnt(0)\n\ts_branch .Lka_we_%=\n"
+                     ".Lka_w0_%=:\n\ts_waitcnt vmcnt(%1)\n\ts_branch .Lka_we_%=\n"
+                     ".Lka_w1_%=:\n\ts_waitcnt vmcnt(%1+1)\n\ts_branch .Lka_we_%=\n"
+                     ".Lka_w2_%=:\n\ts_waitcnt vmcnt(%1+2)\n\ts_branch .Lka_we_%=\n"
+                     ".Lka_w3_%=:\n\ts_waitcnt vmcnt(%1+3)\n\ts_branch .Lka_we_%=\n"
+                     ".Lka_w4_%=:\n\ts_waitcnt vmcnt(%1+4)\n"
+                     ".Lka_we_%=:"
+                     : : "s"(younger), "i"(kIssued) : "memory", "scc");
+    };
     bool stale = false;
-    auto land_regs = [&](uint32_t slot) {
+    // block k has landed in LDS: the finiteness sum over its rows, and (KA_TP_VERIFY=1: the host filled the halo region
+    // with a NaN pattern no score can have) no packet this tile is going to consume may still hold that pattern
+    auto landed_block = [&](int32_t k) {
+        const uint32_t slot = ring(k);
+        const uint32_t r = c.lds_rows + slot * (kTpBlock * kTpRowBytes) + (uint32_t)lane * 4u;
+#pragma unroll
+        for (int f = 0; f < kTpBlock; ++f) c.absum += __builtin_fabsf(lds_f32(r + f * kTpRowBytes));
         if (verify & 1) {
-            // KA_TP_VERIFY=1: the host filled the halo region with a NaN pattern no score can have; a packet this tile
-            // is about to consume that still holds it was read before the tile below had written it
-            const uint32_t sidx = landing_tb + (uint32_t)(lane & (kTpBlock - 1));
-            const bool mine = lane < kTpBlock && (int32_t)sidx >= c.t_in && (int32_t)sidx < c.t_end;
-            const bool bad = mine && (__builtin_bit_cast(uint32_t, hreg[1]) == kTpSentinel || __builtin_bit_cast(uint32_t, hreg[2]) == kTpSentinel ||
-                                      __builtin_bit_cast(uint32_t, hreg[3]) == kTpSentinel);
+            const int32_t sidx = k * kTpBlock + (lane & (kTpBlock - 1));
+            const f32x4 h = lds_f32x4(c.lds_halo + slot * (kTpBlock * 16) + (uint32_t)(lane & (kTpBlock - 1)) * 16u);
+            const bool mine = lane < kTpBlock && sidx >= c.t_in && sidx < c.t_end;
+            const bool bad = mine && (__builtin_bit_cast(uint32_t, h[1]) == kTpSentinel || __builtin_bit_cast(uint32_t, h[2]) == kTpSentinel ||
+                                      __builtin_bit_cast(uint32_t, h[3]) == kTpSentinel);
             if (__builtin_amdgcn_ballot_w64(bad)) stale = true;
         }
-        __attribute__((address_space(3))) float *r = (__attribute__((address_space(3))) float *)(uintptr_t)(c.lds_rows + slot * (kTpBlock * kTpRowBytes));
-#pragma unroll
-        for (int f = 0; f < kTpBlock; ++f) {
-            r[f * 64 + lane] = rows[f];
-            c.absum += __builtin_fabsf(rows[f]);
-        }
-        if (lane < kTpBlock) {
-            __attribute__((address_space(3))) f32x4 *h = (__attribute__((address_space(3))) f32x4 *)(uintptr_t)(c.lds_halo + slot * (kTpBlock * 16));
-            h[lane] = hreg;
-        }
     };
-    // ONE land site and ONE issue site in the whole function (the loop below starts two blocks early to prime the
-    // pipeline): with several, hipcc merges the in-flight registers of the different paths with v_mov copies that
-    // read them before their loads have landed (tools/lint_inflight.py).  The first statement
-    // holds the counted wait - the count is a run-time value, so it is a small scalar branch tree around four
-    // s_waitcnt - and, vmcnt being in order, retires every load of the block; the other registers are released by
-    // statements without instructions.
-    auto land_block = [&](uint32_t slot, uint32_t younger) {
-        landing_tb = issued_tb;
-        asm volatile("s_cmp_ge_u32 %1, %2\n\t"
-                     "s_cbranch_scc1 .Lka_tp_w17_%=\n\t"
-                     "s_cmp_eq_u32 %1, %3\n\t"
-                     "s_cbranch_scc1 .Lka_tp_w16_%=\n\t"
-                     "s_cmp_ge_u32 %1, 1\n\t"
-                     "s_cbranch_scc1 .Lka_tp_w1_%=\n\t"
-                     "s_waitcnt vmcnt(0)\n\t"
-                     "s_branch .Lka_tp_wend_%=\n"
-                     ".Lka_tp_w1_%=:\n\t"
-                     "s_waitcnt vmcnt(1)\n\t"
-                     "s_branch .Lka_tp_wend_%=\n"
-                     ".Lka_tp_w16_%=:\n\t"
-                     "s_waitcnt vmcnt(%3)\n\t"
-                     "s_branch .Lka_tp_wend_%=\n"
-                     ".Lka_tp_w17_%=:\n\t"
-                     "s_waitcnt vmcnt(%2)\n"
-                     ".Lka_tp_wend_%=:"
-                     : "+v"(rows[0]) : "s"(younger), "i"(kTpBlock + 1), "i"(kTpBlock) : "memory", "scc");
-#pragma unroll
-        for (int f = 1; f < kTpBlock; ++f) asm volatile("" : "+v"(rows[f]) : : "memory");
-        asm volatile("" : "+v"(hreg) : : "memory");
-        asm volatile("" : "+v"(pv) : : "memory");
-        land_regs(slot);
-    };
-    // slots the tile below must have published before the halo loads of block tb may be issued
-    auto need_for = [&](uint32_t tb) {
-        const uint32_t n = tb + kTpBlock;
+    // slots the tile below must have published before the halo packets of the block starting at frame tb may be fetched
+    auto need_for = [&](int32_t k) {
+        const uint32_t n = (uint32_t)(k + 1) * kTpBlock;
         return n < (uint32_t)c.t_end ? n : (uint32_t)c.t_end;
     };
 
     const int32_t kb0 = c.t_in / kTpBlock, kb1 = (c.t_end - 1) / kTpBlock;   // first and last block
-    uint32_t younger = 0;   // vector-memory operations issued since the last issue_block
+    uint32_t tail1 = 0, tail2 = 0;   // stores issued behind the issue_block of the previous iteration / the one before (lower bounds)
     bool fed = true;
     TpIn cur = {f32x2{0.0f, 0.0f}, 0.0f, f32x4{NINF, NINF, NINF, NINF}}, nxt = cur;
     float H[3] = {NINF, NINF, NINF};
-    // iteration kb: block kb+1 lands, block kb+2 is requested, block kb is computed.  Iterations kb0-2 and kb0-1 only
-    // prime the pipeline (nothing to land in the first, nothing to compute in either).
-    for (int32_t kb = kb0 - 2; kb <= kb1; ++kb) {
-        const uint32_t tb = (uint32_t)(kb * kTpBlock);              // (wraps for the priming iterations of block 0: not used there)
-        const uint32_t slot = (uint32_t)(kb + 3) % kTpRing, nslot = (uint32_t)(kb + 4) % kTpRing;
-        // block kb+1 has landed -> LDS; publish what the wait has retired; poll; request block kb+2
-        if (kb >= kb0 - 1) land_block(nslot, (verify & 2) ? 0u : younger);   // (KA_TP_VERIFY=2/3: full drain, to tell a counting error from a hand-off error)
-        // retired: everything issued before the loads of block kb+1, i.e. the halo stores of blocks <= kb-2 = slots <= 16 (kb-1)
-        if (kb >= kb0 + 2) tp_prog_store(c.prog_out, tb - kTpBlock + 1);
-        if (kb + 2 <= kb1 && fed)
-            fed = tp_wait_progress(c.prog_in, need_for((uint32_t)((kb + 2) * kTpBlock)), need_for((uint32_t)((kb + 4) * kTpBlock)), (uint32_t)__builtin_amdgcn_readfirstlane((int)pv), st);
-        issue_block((uint32_t)((kb + 2) * kTpBlock));
-        younger = 0;
-        if (kb < kb0) continue;
+    // iteration it: block it+1 has landed (requested two iterations ago), block it+3 is requested, block it is computed.
+    // Iterations kb0-3 .. kb0-1 only prime the pipeline.
+    for (int32_t it = kb0 - 3; it <= kb1; ++it) {
+        const uint32_t tb = (uint32_t)(it * kTpBlock);              // (wraps in the priming iterations of block 0: not used there)
+        if (it >= kb0 - 1) {
+            wait_landed((verify & 2) ? 0u : kIssued + tail1 + tail2);   // younger: one issue_block and the stores behind the last two
+            landed_block(it + 1);
+        }
+        // retired by that wait: everything issued before the requests of iteration it-2, i.e. the packets of blocks <= it-3 = slots <= 16 (it-2)
+        if (it >= kb0 + 3) tp_prog_store(c.prog_out, tb - 2 * kTpBlock + 1);
+        if (it + 3 <= kb1 && fed) {
+            // the freshest look at the progress word that has landed is the one requested two iterations ago (with block it+1)
+            const uint32_t have = it >= kb0 - 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_bit_cast(uint32_t, lds_f32(lds_poll + ring(it + 1) * 4))) : 0u;
+            fed = tp_wait_progress(c.prog_in, need_for(it + 3), need_for(it + 5), have, stat_lds);
+        }
+        if (it + 3 >= 0) issue_block(it + 3);
+        tail2 = tail1;
+        tail1 = 0;
+        if (it < kb0) continue;
+        const uint32_t slot = ring(it), nslot = ring(it + 1);
         // (LDS addresses live in vector registers: say so once per block instead of a v_mov per read)
         uint32_t rc = c.lds_rows + slot * (kTpBlock * kTpRowBytes), rn = c.lds_rows + nslot * (kTpBlock * kTpRowBytes);
         uint32_t hc = c.lds_halo + slot * (kTpBlock * 16), hn = c.lds_halo + nslot * (kTpBlock * 16);
@@ -471,7 +498,7 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
         TpAddr A[2] = {{rc + (uint32_t)c.la0, rc + (uint32_t)c.la1, rc, hc}, {rn + (uint32_t)c.la0, rn + (uint32_t)c.la1, rn, hn}};
         asm volatile("" : "+v"(A[0].l0), "+v"(A[0].l1), "+v"(A[1].l0), "+v"(A[1].l1));   // (keep the four sums: no re-add per frame)
         c.out_block = c.halo_out + ((int64_t)tb - (int64_t)c.t_in) * 16;
-        if (kb == kb0) {
+        if (it == kb0) {
             // prime the two-frame read pipeline at the block's frames 0 and 1; when the tile starts later in the block,
             // the skipped frames in front of it shift the pipeline along (and take H afresh) exactly like computed ones
             cur.E = f32x2{lds_f32(A[0].l0), lds_f32(A[0].l1)};
@@ -486,16 +513,21 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
         }
         const bool partial = (int32_t)tb < c.t_in || (int32_t)(tb + kTpBlock) > c.t_end;
         if (!partial) {
-            tp_block_frames<M, ZL, false, 0>(c, tb, H, cur, nxt, A, lane63, NINF);
-            younger = kTpBlock;
+            const unsigned long long fr0 = (verify & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
+            tp_block_frames<M, ZL, false, 0>(c, tb, H, cur, nxt, A, NINF);
+            if (verify & 4) ((__attribute__((address_space(3))) uint32_t *)(uintptr_t)stat_lds)[2] += (uint32_t)(__builtin_amdgcn_s_memtime() - fr0);
+            tp_publish_block(c, tb, lane);
+            tail1 = 1;
             if ((tb & kTpBlock) && tb + kTpBlock < c.T) {
                 tp_checkpoint(c, tb + kTpBlock);
-                ++younger;
+                ++tail1;
             }
         } else {
-            tp_block_frames<M, ZL, true, 0>(c, tb, H, cur, nxt, A, lane63, NINF);
+            tp_block_frames<M, ZL, true, 0>(c, tb, H, cur, nxt, A, NINF);
+            tp_publish_block(c, tb, lane);
             if ((tb & kTpBlock) && (int32_t)(tb + kTpBlock) <= c.t_end && tb + kTpBlock < c.T) tp_checkpoint(c, tb + kTpBlock);
-            // (a partial block issued an unknown number of stores: younger stays 0 and the next wait drains everything)
+            // (a partial block issued an unknown number of stores: its count stays 0, a lower bound, and the waits that
+            //  cover it wait for a store or two more than they must)
         }
     }
     // drain the staging loads still in flight (their registers are dead to the compiler after the loop and would be
@@ -522,7 +554,15 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
         tp_prog_store(c.prog_out, kTpProgDone);
     }
     if ((verify & 4) && lane == 0) {
-        st.total_ticks = wall_clock64() - st.start_tick;
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const __attribute__((address_space(3))) uint32_t *sw = (const __attribute__((address_space(3))) uint32_t *)(uintptr_t)stat_lds;
+        TpStats st;
+        st.spins = sw[0] | ((unsigned long long)((xcc & 0xf) << 16 | (hw & 0xffff))) << 32;   // where the tile ran: XCC, SE/SH/CU/SIMD/wave slot
+        st.wait_ticks = sw[1] | ((unsigned long long)sw[2] << 32);   // (high half: shader cycles inside the unguarded frame blocks)
+        st.start_tick = __builtin_amdgcn_s_memtime() - stats_out->total_ticks;   // (the tile's shader cycles)
+        st.total_ticks = wall_clock64() - stats_out->start_tick;
         *stats_out = st;
     }
     // ---- terminal state: the HIGHEST live position of frame T-1 (align.py:99-101), over the tiles alive then ----
@@ -567,7 +607,7 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
 // finish.  The tile a workgroup runs is drawn from a ticket counter, not from its index: tasks are sorted by first frame,
 // so whatever order the dispatcher starts workgroups in, a tile's producer holds an earlier ticket and is running or done
 // - the earliest unfinished ticket can always run to completion.
-constexpr unsigned kTpLdsRequest = 40 * 1024;
+constexpr unsigned kTpLdsRequest = 40 * 1024;   // used: 16 KB rows + 1 KB packets + 16 KB publish staging
 template <int M>
 __global__ __launch_bounds__(64) void forward_tp_kernel(const Lattice *__restrict__ lats, const TileTask *__restrict__ tasks, int n_tasks,
                                                         int32_t *meta, char *halo, uint32_t *prog, TileAux *aux, uint32_t *ticket, int verify, TpStats *stats)
