@@ -673,12 +673,24 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
         ka::TileAux *d_aux = reinterpret_cast<ka::TileAux *>(e->ws + off_aux);
         uint32_t *d_ticket = reinterpret_cast<uint32_t *>(e->ws + off_ticket);
         ka::TpStats *d_stats = reinterpret_cast<ka::TpStats *>(e->ws + off_stats);
-        switch (max_move) {
-        case 1: hipLaunchKernelGGL((ka::forward_tp_kernel<1>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket, verify, d_stats); break;
-        case 2: hipLaunchKernelGGL((ka::forward_tp_kernel<2>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket, verify, d_stats); break;
-        case 3: hipLaunchKernelGGL((ka::forward_tp_kernel<3>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket, verify, d_stats); break;
-        default: hipLaunchKernelGGL((ka::forward_tp_kernel<4>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket, verify, d_stats); break;
+        // staging mode: when every tiled lattice's rows are contiguous (row stride = V, V = 64 or 39, 16-byte aligned) a block
+        // is copied as it lies in memory (1 KB per LDS-DMA instruction); otherwise row by row
+        int pitch = ((V == 64 || V == 39) && max_move == 4) ? 4 * V : 0;   // 0: row by row
+        for (int32_t k = 0; k < n_tiled && pitch; ++k) {
+            const int32_t i = order[k];
+            const bool contiguous = mem == KA_MEM_HOST || (ld[i] == V && ((uintptr_t)log_probs[i] & 15) == 0);
+            if (!contiguous) pitch = 0;
         }
+#define KA_TP_LAUNCH(MM, PP, CC) hipLaunchKernelGGL((ka::forward_tp_kernel<MM, PP, CC>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket, verify, d_stats)
+        if (pitch == 256 && V == 64) KA_TP_LAUNCH(4, 256, true);
+        else if (pitch == 156) KA_TP_LAUNCH(4, 156, true);
+        else switch (max_move) {
+        case 1: KA_TP_LAUNCH(1, 256, false); break;
+        case 2: KA_TP_LAUNCH(2, 256, false); break;
+        case 3: KA_TP_LAUNCH(3, 256, false); break;
+        default: KA_TP_LAUNCH(4, 256, false); break;
+        }
+#undef KA_TP_LAUNCH
         form = kFormWaveCheckpointed;
     }
     if (n_fast > 0) {
@@ -871,6 +883,9 @@ int ka_debug_tile_stats(ka_engine *e, uint64_t *out, int32_t max_tasks)
         uint64_t *o = out + 8 * i;
         o[0] = (uint64_t)tk[i].lat; o[1] = (uint64_t)tk[i].tile; o[2] = (uint64_t)tk[i].t_in; o[3] = (uint64_t)tk[i].t_end;
         o[4] = st[i].wait_ticks; o[5] = st[i].total_ticks; o[6] = st[i].spins; o[7] = st[i].start_tick;
+        if (i == 0 || i == 10 || i == 20) std::fprintf(stderr, "[ka_debug_tile_stats] ticket %zu cycles per phase: wait %llu, check+sum %llu, progress %llu, requests %llu, publish %llu\n", i,
+                                 (unsigned long long)(uint32_t)st[i].phase[0], (unsigned long long)(st[i].phase[0] >> 32), (unsigned long long)(uint32_t)st[i].phase[1],
+                                 (unsigned long long)(st[i].phase[1] >> 32), (unsigned long long)st[i].phase[2]);
     }
     return (int)n;
 }

@@ -31,7 +31,8 @@ constexpr int kTpCells = 4;                    // cells per lane
 constexpr int kTpTile = 64 * kTpCells;         // positions per tile
 constexpr int kTpBlock = 16;                   // frames per staging block
 constexpr int kTpRing = 4;                     // LDS staging slots: the block being computed, the next one (landed), two more in flight
-constexpr int kTpRowBytes = 256;               // LDS pitch of a staged row (64 columns)
+constexpr int kTpRowBytes = 256;               // LDS pitch of a staged row in the row-by-row staging mode (64 columns)
+constexpr int kTpSlotBytes = 4096;             // LDS bytes of a staged block of 16 rows (any mode)
 constexpr uint32_t kTpSentinel = 0x7fc0deadu;  // verification fill of the halo region (a NaN: no score is ever NaN)
 constexpr uint32_t kTpProgDone = 0x7fffffffu;  // progress word of a finished tile / of "no tile below"
 static_assert(kCkFrames == 2 * kTpBlock, "a checkpoint is taken at the end of every second block");
@@ -98,6 +99,16 @@ __device__ __forceinline__ void tp_mask_toggle(TpMasks &mk, int32_t rel)
     mk.m2 ^= k == 2 ? bit : 0ull;
     mk.m3 ^= k == 3 ? bit : 0ull;
 }
+// -inf into the cell at tile-relative position rel (0..255): S = {cell 0, 2, 1, 3} of lane rel >> 2
+__device__ __forceinline__ void tp_kill(f32x4 &S, uint32_t rel, float NINF)
+{
+    const uint64_t m = 1ull << (rel >> 2);
+    const uint32_t k = rel & 3u;
+    S[0] = select_by_mask(S[0], NINF, k == 0 ? m : 0ull);
+    S[2] = select_by_mask(S[2], NINF, k == 1 ? m : 0ull);
+    S[1] = select_by_mask(S[1], NINF, k == 2 ? m : 0ull);
+    S[3] = select_by_mask(S[3], NINF, k == 3 ? m : 0ull);
+}
 // state of a lane: S = {cell 0, cell 2, cell 1, cell 3} = {blank, blank, label, label} - the two blanks and the two labels
 // are register pairs (v_pk_add_f32 of the emissions), and the four registers as they lie ARE the halo packet
 __device__ __forceinline__ void tp_mask_state(f32x4 &S, const TpMasks &mk, float NINF)
@@ -118,24 +129,24 @@ __device__ __forceinline__ void tp_halo_store(const void *block_base /* uniform 
     // registers for two more wait states: the EXEC restore and the s_nop are those.
     uint64_t saved;
 #if defined(KA_TP_EXP) && KA_TP_EXP == 1   // timing experiment only (results wrong across XCDs): plain stores
-    asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %4\n\tglobal_store_dwordx4 %1, %2, %3 offset:%5\n\ts_mov_b64 exec, %0\n\ts_nop 0"
+    asm volatile("s_nop 4\n\ts_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %4\n\tglobal_store_dwordx4 %1, %2, %3 offset:%5\n\ts_mov_b64 exec, %0\n\ts_nop 0"
                  : "=&s"(saved) : "v"(0u), "v"(pk), "s"(block_base), "s"(lane_mask), "i"(OFF) : "memory", "scc");
 #elif defined(KA_TP_EXP) && KA_TP_EXP == 2   // timing experiment only: no halo stores at all
     (void)saved;
 #else
-    asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %4\n\tglobal_store_dwordx4 %1, %2, %3 offset:%5 sc1\n\ts_mov_b64 exec, %0\n\ts_nop 0"
+    asm volatile("s_nop 4\n\ts_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %4\n\tglobal_store_dwordx4 %1, %2, %3 offset:%5 sc1\n\ts_mov_b64 exec, %0\n\ts_nop 0"
                  : "=&s"(saved) : "v"(0u), "v"(pk), "s"(block_base), "s"(lane_mask), "i"(OFF) : "memory", "scc");
 #endif
 }
 __device__ __forceinline__ void tp_prog_store(gu32w_t word /* uniform */, uint32_t value)
 {
     uint64_t saved;
-    asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, 1\n\tglobal_store_dword %1, %2, %3 sc1\n\ts_mov_b64 exec, %0"
+    asm volatile("s_nop 4\n\ts_mov_b64 %0, exec\n\ts_and_b64 exec, exec, 1\n\tglobal_store_dword %1, %2, %3 sc1\n\ts_mov_b64 exec, %0"
                  : "=&s"(saved) : "v"(0u), "v"(value), "s"(word) : "memory", "scc");
 }
 __device__ __forceinline__ void tp_prog_load(uint32_t &dst, gu32w_t word /* uniform */)
 {
-    asm volatile("global_load_dword %0, %1, %2 sc1" : "+v"(dst) : "v"(0u), "s"(word) : "memory");
+    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 sc1" : "+v"(dst) : "v"(0u), "s"(word) : "memory");
 }
 // progress of the tile below must reach `need` leading slots; polled relaxed with a sleep that grows while far away.
 // Bounded: a tile whose producer has not delivered within ~4 s of wall clock gives up (returns false; the lattice gets
@@ -144,6 +155,7 @@ __device__ __forceinline__ void tp_prog_load(uint32_t &dst, gu32w_t word /* unif
 // start is a block old, so a tile sitting exactly at the limit would pay a poll round trip (~1 us) at every block;
 // after one longer wait it stays ahead of its stale information for as long as it is not faster than its producer.
 struct TpStats {
+    unsigned long long phase[3];   // shader cycles: (wait | check+sum << 32), (progress | requests << 32), (publish+checkpoint)
     unsigned long long wait_ticks, total_ticks, spins, start_tick;   // 100 MHz ticks (KA_TP_VERIFY & 4: ka_debug_tile_stats)
 };
 // (diagnostic counters - number of waits, 100 MHz ticks spent in them - live in two LDS words at `stat_lds`)
@@ -189,8 +201,7 @@ struct TpTile {
     uint32_t ck_off;        // per lane: ((base + 4 lane) & ck_mask) * 4
     // band state of the frame being computed
     uint32_t q, rem, lo, hi, thr;
-    TpMasks mk;
-    bool edge;              // the band does not cover the whole tile: masks matter
+    uint32_t kill_from, kill_to;   // positions that left the band in the previous frame's step and die after this frame (rule ii)
     // per lane
     f32x4 S;
     int la0, la1;           // 4 * label of cells 1 and 3
@@ -242,14 +253,21 @@ __device__ __forceinline__ void tp_frame(TpTile<M, ZL> &c, uint32_t t, float (&H
         mb[0] = cell_blank_max<M>(b0, H[0], H[2]);
         const f32x2 sl = ml + cur.E, sb = mb + f32x2{cur.e0, cur.e0};
         c.S = f32x4{sb[0], sb[1], sl[0], sl[1]};
-        // band of the next frame (align.py:64-65), advanced Bresenham-style; the masks matter only while an edge of
-        // the band is inside this tile: (i) before a band step what becomes live must hold -inf, (ii) in the first frame
-        // of a new band what left it on the lo side must die (see forward_ck; there is no ring here, so no (iii))
+        // band of the next frame (align.py:64-65), advanced Bresenham-style.  The band is enforced by KILLING single cells,
+        // not by masking all of them: a cell above hi collects "leaked" scores from the live cells under it and must hold
+        // -inf at the moment it enters the band (rule i: killed in the frame before the step); a cell that has dropped
+        // below lo was live in the last frame of the old band, is still computed in the first frame of the new one and
+        // must be dead after it (rule ii: killed one frame after the step) - from then on it only reads cells below
+        // itself, which are dead, and stays -inf by itself.  Only positions inside this tile cost anything.
         c.rem += c.dr;
         if (__builtin_expect(c.rem >= c.thr, 0)) {
             asm volatile("" ::: "memory");
             c.thr = c.thr_real();
-            if (c.edge) tp_mask_state(c.S, c.mk, NINF);
+            const uint32_t tile_lo = (uint32_t)c.base, tile_hi = (uint32_t)c.base + kTpTile;
+            if (c.kill_to > c.kill_from) {   // rule ii for the step of the previous frame
+                for (uint32_t p = c.kill_from; p < c.kill_to; ++p) tp_kill(c.S, p - tile_lo, NINF);
+                c.kill_to = c.kill_from = 0;
+            }
             if (c.rem >= c.thr_real()) {
                 c.q += c.dq;
                 if (c.rem >= c.T) { c.rem -= c.T; ++c.q; }
@@ -257,18 +275,17 @@ __device__ __forceinline__ void tp_frame(TpTile<M, ZL> &c, uint32_t t, float (&H
                     const int32_t dlo = (int32_t)c.q - (int32_t)(c.B >> 1);
                     const uint32_t nlo = (uint32_t)(dlo > 0 ? dlo : 0);
                     const uint32_t nhi = (c.L - nlo < c.B) ? c.L : nlo + c.B;
-                    if (nlo != c.lo || nhi != c.hi) {
-                        // the masks follow the band position by position (usually one leaves, one enters; only those
-                        // inside the tile cost anything) - kept up to date always, so there is no rebuild path here
-                        const uint32_t tile_lo = (uint32_t)c.base, tile_hi = (uint32_t)c.base + kTpTile;
-                        for (uint32_t p = c.lo > tile_lo ? c.lo : tile_lo; p < (nlo < tile_hi ? nlo : tile_hi); ++p) tp_mask_toggle(c.mk, (int32_t)(p - tile_lo));
-                        for (uint32_t p = c.hi > tile_lo ? c.hi : tile_lo; p < (nhi < tile_hi ? nhi : tile_hi); ++p) tp_mask_toggle(c.mk, (int32_t)(p - tile_lo));
-                        const bool was_edge = c.edge;
-                        c.lo = nlo;
-                        c.hi = nhi;
-                        c.edge = nlo > tile_lo || nhi < tile_hi;
-                        if (c.edge || was_edge) c.thr = 0;   // frame t+1 is the first of a new band: it must come through here again (rule ii)
+                    // rule i: what enters at the top, now
+                    for (uint32_t p = c.hi > tile_lo ? c.hi : tile_lo; p < (nhi < tile_hi ? nhi : tile_hi); ++p) tp_kill(c.S, p - tile_lo, NINF);
+                    // rule ii: what leaves at the bottom, after the next frame
+                    const uint32_t a = c.lo > tile_lo ? c.lo : tile_lo, b2 = nlo < tile_hi ? nlo : tile_hi;
+                    if (b2 > a) {
+                        c.kill_from = a;
+                        c.kill_to = b2;
+                        c.thr = 0;   // frame t+1 must come through here again
                     }
+                    c.lo = nlo;
+                    c.hi = nhi;
                 }
             }
         }
@@ -295,14 +312,13 @@ __device__ __forceinline__ void tp_frame(TpTile<M, ZL> &c, uint32_t t, float (&H
 struct TpAddr {
     uint32_t l0, l1, r, h;
 };
-template <int M, bool ZL, bool GUARDED, int F>
+template <int M, bool ZL, int PITCH, bool GUARDED, int F>
 __device__ __forceinline__ void tp_block_frames(TpTile<M, ZL> &c, uint32_t tb, float (&H)[3], TpIn &cur, TpIn &nxt, const TpAddr (&A)[2], float NINF)
 {
     // frame t+2 = F+2 of this block, or F+2-16 of the next one
     constexpr int F2 = (F + 2) % kTpBlock, W = (F + 2) / kTpBlock;
-    tp_frame<M, ZL, GUARDED, F>(c, tb + F, H, cur, nxt, A[W].l0 + F2 * kTpRowBytes, A[W].l1 + F2 * kTpRowBytes, A[W].r + F2 * kTpRowBytes, A[W].h + F2 * 16,
-                                NINF);
-    if constexpr (F + 1 < kTpBlock) tp_block_frames<M, ZL, GUARDED, F + 1>(c, tb, H, cur, nxt, A, NINF);
+    tp_frame<M, ZL, GUARDED, F>(c, tb + F, H, cur, nxt, A[W].l0 + F2 * PITCH, A[W].l1 + F2 * PITCH, A[W].r + F2 * PITCH, A[W].h + F2 * 16, NINF);
+    if constexpr (F + 1 < kTpBlock) tp_block_frames<M, ZL, PITCH, GUARDED, F + 1>(c, tb, H, cur, nxt, A, NINF);
 }
 
 // end of a block: lane f < 16 fetches what lane 63 staged in frame f and stores it as slot tb + f + 1 (one write-through
@@ -313,7 +329,7 @@ __device__ __forceinline__ void tp_publish_block(TpTile<M, ZL> &c, uint32_t tb, 
     const int32_t t = (int32_t)tb + lane;
     if (lane < kTpBlock && t >= c.t_in && t < c.t_end) {
         const f32x4 pk = lds_f32x4(c.lds_stage - (uint32_t)lane * 16u + (uint32_t)lane * 1024u + 63u * 16u);
-        asm volatile("global_store_dwordx4 %0, %1, %2 offset:16 sc1\n\ts_nop 1" : : "v"((uint32_t)lane * 16u), "v"(pk), "s"(c.out_block) : "memory");
+        asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:16 sc1\n\ts_nop 1" : : "v"((uint32_t)lane * 16u), "v"(pk), "s"(c.out_block) : "memory");
     }
 }
 
@@ -321,18 +337,33 @@ template <int M, bool ZL>
 __device__ __forceinline__ void tp_checkpoint(TpTile<M, ZL> &c, uint32_t t_next /* multiple of 32 */)
 {
     const f32x4 v = {c.S[0], c.S[2], c.S[1], c.S[3]};   // cells 0..3 in position order
-    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(c.ck_off), "v"(v), "s"(c.ck + ((size_t)(t_next / kCkFrames) - 1) * (size_t)c.ck_pitch) : "memory");
+    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(c.ck_off), "v"(v), "s"(c.ck + ((size_t)(t_next / kCkFrames) - 1) * (size_t)c.ck_pitch) : "memory");
 }
 
 // ---------------------------------------------------------------------------------------
 // one tile, all its frames
 // ---------------------------------------------------------------------------------------
-template <int M, bool ZL>
+// PITCH = bytes between two rows of a staged block in LDS.  CONTIG = false (PITCH 256): rows are staged one by one
+// (lane = column; any row stride of the caller's array).  CONTIG = true (PITCH = 4 V; the array's rows are contiguous, V
+// columns): a block is copied as it lies in memory, 1 KB per LDS-DMA instruction - 4 (V = 64) or 3 (V = 39) instructions per block instead of 16; an LDS-DMA
+// instruction costs the wave ~60 cycles to issue whatever it moves, and with 16 of them the per-block staging took
+// longer than the block's 16 frames.
+template <int M, bool ZL, int PITCH, bool CONTIG>
 __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk, int32_t *meta, char *halo, gu32w_t prog, TileAux *aux,
                                             uint32_t lds_rows, uint32_t lds_halo, int verify, TpStats *stats_out)
 {
     const uint32_t stat_lds = lds_halo + kTpRing * kTpBlock * 16 + 16 + kTpBlock * 1024;   // diagnostic words behind the staging areas
-    if (threadIdx.x < 3) ((__attribute__((address_space(3))) uint32_t *)(uintptr_t)stat_lds)[threadIdx.x] = 0;
+    if (threadIdx.x < 8) ((__attribute__((address_space(3))) uint32_t *)(uintptr_t)stat_lds)[threadIdx.x] = 0;
+    // (KA_TP_VERIFY=4) shader cycles per phase of the block loop: [3] wait for the staged block, [4] its check + finiteness
+    // sum, [5] progress store + poll, [6] requests (LDS-DMA issue), [7] publish + checkpoint
+    unsigned long long ph = 0;
+    auto phase = [&](int w) {
+        if (verify & 4) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (w >= 0) ((__attribute__((address_space(3))) uint32_t *)(uintptr_t)stat_lds)[w] += (uint32_t)(now - ph);
+            ph = now;
+        }
+    };
     if (verify & 4) {   // start stamps: wall clock (100 MHz) and shader clock
         stats_out->start_tick = (unsigned long long)wall_clock64();
         stats_out->total_ticks = __builtin_amdgcn_s_memtime();
@@ -369,8 +400,7 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
         const int32_t dlo = (int32_t)c.q - (int32_t)(c.B >> 1);
         c.lo = (uint32_t)(dlo > 0 ? dlo : 0);
         c.hi = (c.L - c.lo < c.B) ? c.L : c.lo + c.B;
-        c.edge = (int32_t)c.lo > c.base || (int32_t)c.hi < c.base + kTpTile;
-        tp_masks(c.mk, (int32_t)c.lo - c.base, (int32_t)c.hi - c.base);
+        c.kill_from = c.kill_to = 0;
         c.thr = c.thr_real();
         asm("" : "+s"(c.thr));
     }
@@ -400,21 +430,38 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
     const uint32_t last_slot = (uint32_t)c.t_end - 1;     // this tile reads slots t_in .. t_end - 1
     const uint32_t lds_poll = c.lds_halo + kTpRing * kTpBlock * 16;
     auto ring = [](int32_t k) { return (uint32_t)((k % kTpRing + kTpRing) % kTpRing); };
+    constexpr int kRowDmas = !CONTIG ? kTpBlock : (kTpBlock * PITCH + 1023) / 1024;   // LDS-DMA instructions per block of rows
+    static_assert(CONTIG || PITCH == kTpRowBytes, "row-by-row staging uses 256-byte rows");
     auto issue_block = [&](int32_t k) {    // k >= 0
         const uint32_t tb = (uint32_t)k * kTpBlock, slot = ring(k);
-        const char *rp = c.lp + (size_t)(tb < last_row ? tb : last_row) * c.ld;   // wave-uniform; the lane's column is a 32-bit offset
-        lchar_t dst = (lchar_t)(uintptr_t)(c.lds_rows + slot * (kTpBlock * kTpRowBytes));
-        if (tb + kTpBlock <= c.T) {      // every row of the block exists (nothing in flight lives in a register: two paths are fine here)
+        lchar_t dst = (lchar_t)(uintptr_t)(c.lds_rows + slot * kTpSlotBytes);
+        if constexpr (!CONTIG) {
+            const char *rp = c.lp + (size_t)(tb < last_row ? tb : last_row) * c.ld;   // wave-uniform; the lane's column is a 32-bit offset
+            if (tb + kTpBlock <= c.T) {      // every row of the block exists (nothing in flight lives in a register: two paths are fine here)
 #pragma unroll
-            for (int f = 0; f < kTpBlock; ++f) {
-                __builtin_amdgcn_global_load_lds((gptr_t)(rp + c.lane_off), (lptr_t)(dst + f * kTpRowBytes), 4, 0, 0);   // row tb+f: lane = column, 256 B
-                rp += c.ld;
+                for (int f = 0; f < kTpBlock; ++f) {
+                    __builtin_amdgcn_global_load_lds((gptr_t)(rp + c.lane_off), (lptr_t)(dst + f * kTpRowBytes), 4, 0, 0);   // row tb+f: lane = column, 256 B
+                    rp += c.ld;
+                }
+            } else {                         // the lattice's last rows, and blocks requested past them: stop at row T-1
+#pragma unroll
+                for (int f = 0; f < kTpBlock; ++f) {
+                    __builtin_amdgcn_global_load_lds((gptr_t)(rp + c.lane_off), (lptr_t)(dst + f * kTpRowBytes), 4, 0, 0);
+                    rp += tb + f < last_row ? c.ld : 0;
+                }
             }
-        } else {                         // the lattice's last rows, and blocks requested past them: stop at row T-1
+        } else {
+            // the block as it lies in memory: 16 rows x PITCH bytes from row tb on, 16 bytes per lane and instruction;
+            // past the lattice's last row the lanes re-read its last 16 aligned bytes (rows that do not exist are not used)
+            const uint32_t first = tb < last_row ? tb : last_row;
+            const uint32_t rows_there = c.T - first < (uint32_t)kTpBlock ? c.T - first : (uint32_t)kTpBlock;
+            const uint32_t last_chunk = (rows_there * PITCH - 16u) & ~15u;
+            const char *bp = c.lp + (size_t)first * PITCH;
 #pragma unroll
-            for (int f = 0; f < kTpBlock; ++f) {
-                __builtin_amdgcn_global_load_lds((gptr_t)(rp + c.lane_off), (lptr_t)(dst + f * kTpRowBytes), 4, 0, 0);
-                rp += tb + f < last_row ? c.ld : 0;
+            for (int j = 0; j < kRowDmas; ++j) {
+                uint32_t off = (uint32_t)j * 1024u + (uint32_t)lane * 16u;
+                off = off < last_chunk ? off : last_chunk;
+                __builtin_amdgcn_global_load_lds((gptr_t)(bp + off), (lptr_t)(dst + j * 1024), 16, 0, 0);
             }
         }
         if (lane < kTpBlock) {       // slots tb .. tb+15 of the lower boundary (clamped to what exists): 16 lanes x 16 B, write-through data: sc1
@@ -424,7 +471,7 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
         }
         if (lane == 0) __builtin_amdgcn_global_load_lds((gptr_t)c.prog_in, (lptr_t)(lchar_t)(uintptr_t)(lds_poll + slot * 4), 4, 0, 16);
     };
-    constexpr int kIssued = kTpBlock + 2;   // vector-memory instructions of one issue_block
+    constexpr int kIssued = kRowDmas + 2;   // vector-memory instructions of one issue_block
     // everything issued by the issue_block of TWO iterations ago has landed once at most `younger` younger operations
     // are in flight (vmcnt is an in-order counter; never pass more than were really issued since)
     auto wait_landed = [&](uint32_t younger) {
@@ -447,9 +494,19 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
     // with a NaN pattern no score can have) no packet this tile is going to consume may still hold that pattern
     auto landed_block = [&](int32_t k) {
         const uint32_t slot = ring(k);
-        const uint32_t r = c.lds_rows + slot * (kTpBlock * kTpRowBytes) + (uint32_t)lane * 4u;
+        // (all reads first, then the sum: written as one accumulation chain hipcc waited for every read in turn -
+        //  1700 cycles per block, more than the block's 16 frames)
+        const uint32_t r = c.lds_rows + slot * kTpSlotBytes + (uint32_t)lane * 4u;
+        constexpr int kReads = !CONTIG ? kTpBlock : (kTpBlock * PITCH + 255) / 256;
+        float v[kReads];
 #pragma unroll
-        for (int f = 0; f < kTpBlock; ++f) c.absum += __builtin_fabsf(lds_f32(r + f * kTpRowBytes));
+        for (int j = 0; j < kReads; ++j) v[j] = lds_f32(r + j * 256);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < kReads; ++j) {
+            const bool real = !CONTIG || j * 256 + 252 < kTpBlock * PITCH || j * 256 + lane * 4 < kTpBlock * PITCH;   // (past the block's last row: not a log-prob)
+            c.absum += real ? __builtin_fabsf(v[j]) : 0.0f;
+        }
         if (verify & 1) {
             const int32_t sidx = k * kTpBlock + (lane & (kTpBlock - 1));
             const f32x4 h = lds_f32x4(c.lds_halo + slot * (kTpBlock * 16) + (uint32_t)(lane & (kTpBlock - 1)) * 16u);
@@ -474,9 +531,12 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
     // Iterations kb0-3 .. kb0-1 only prime the pipeline.
     for (int32_t it = kb0 - 3; it <= kb1; ++it) {
         const uint32_t tb = (uint32_t)(it * kTpBlock);              // (wraps in the priming iterations of block 0: not used there)
+        phase(-1);
         if (it >= kb0 - 1) {
             wait_landed((verify & 2) ? 0u : kIssued + tail1 + tail2);   // younger: one issue_block and the stores behind the last two
+            phase(3);
             landed_block(it + 1);
+            phase(4);
         }
         // retired by that wait: everything issued before the requests of iteration it-2, i.e. the packets of blocks <= it-3 = slots <= 16 (it-2)
         if (it >= kb0 + 3) tp_prog_store(c.prog_out, tb - 2 * kTpBlock + 1);
@@ -485,13 +545,15 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
             const uint32_t have = it >= kb0 - 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_bit_cast(uint32_t, lds_f32(lds_poll + ring(it + 1) * 4))) : 0u;
             fed = tp_wait_progress(c.prog_in, need_for(it + 3), need_for(it + 5), have, stat_lds);
         }
+        phase(5);
         if (it + 3 >= 0) issue_block(it + 3);
+        phase(6);
         tail2 = tail1;
         tail1 = 0;
         if (it < kb0) continue;
         const uint32_t slot = ring(it), nslot = ring(it + 1);
         // (LDS addresses live in vector registers: say so once per block instead of a v_mov per read)
-        uint32_t rc = c.lds_rows + slot * (kTpBlock * kTpRowBytes), rn = c.lds_rows + nslot * (kTpBlock * kTpRowBytes);
+        uint32_t rc = c.lds_rows + slot * kTpSlotBytes, rn = c.lds_rows + nslot * kTpSlotBytes;
         uint32_t hc = c.lds_halo + slot * (kTpBlock * 16), hn = c.lds_halo + nslot * (kTpBlock * 16);
         asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
                      : "=&v"(rc), "=&v"(rn), "=&v"(hc), "=&v"(hn) : "s"(rc), "s"(rn), "s"(hc), "s"(hn));
@@ -503,8 +565,8 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
             // the skipped frames in front of it shift the pipeline along (and take H afresh) exactly like computed ones
             cur.E = f32x2{lds_f32(A[0].l0), lds_f32(A[0].l1)};
             cur.e0 = lds_f32(A[0].r);
-            nxt.E = f32x2{lds_f32(A[0].l0 + kTpRowBytes), lds_f32(A[0].l1 + kTpRowBytes)};
-            nxt.e0 = lds_f32(A[0].r + kTpRowBytes);
+            nxt.E = f32x2{lds_f32(A[0].l0 + PITCH), lds_f32(A[0].l1 + PITCH)};
+            nxt.e0 = lds_f32(A[0].r + PITCH);
             nxt.hp = lds_f32x4(A[0].h + 16);
             const f32x4 hp = lds_f32x4(A[0].h);
             H[0] = wave_shr1(hp[3], c.S[3]);
@@ -514,16 +576,18 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
         const bool partial = (int32_t)tb < c.t_in || (int32_t)(tb + kTpBlock) > c.t_end;
         if (!partial) {
             const unsigned long long fr0 = (verify & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
-            tp_block_frames<M, ZL, false, 0>(c, tb, H, cur, nxt, A, NINF);
+            tp_block_frames<M, ZL, PITCH, false, 0>(c, tb, H, cur, nxt, A, NINF);
             if (verify & 4) ((__attribute__((address_space(3))) uint32_t *)(uintptr_t)stat_lds)[2] += (uint32_t)(__builtin_amdgcn_s_memtime() - fr0);
+            phase(-1);
             tp_publish_block(c, tb, lane);
             tail1 = 1;
             if ((tb & kTpBlock) && tb + kTpBlock < c.T) {
                 tp_checkpoint(c, tb + kTpBlock);
                 ++tail1;
             }
+            phase(7);
         } else {
-            tp_block_frames<M, ZL, true, 0>(c, tb, H, cur, nxt, A, NINF);
+            tp_block_frames<M, ZL, PITCH, true, 0>(c, tb, H, cur, nxt, A, NINF);
             tp_publish_block(c, tb, lane);
             if ((tb & kTpBlock) && (int32_t)(tb + kTpBlock) <= c.t_end && tb + kTpBlock < c.T) tp_checkpoint(c, tb + kTpBlock);
             // (a partial block issued an unknown number of stores: its count stays 0, a lower bound, and the waits that
@@ -549,7 +613,7 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
     {
         const f32x4 dead = {NINF, NINF, NINF, NINF};
         for (int64_t s = (int64_t)c.t_end + 1 + lane; s <= (int64_t)tk.fill_end; s += 64)
-            asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" : : "v"((uint32_t)((s - c.t_in) * 16)), "v"(dead), "s"(c.halo_out) : "memory");
+            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" : : "v"((uint32_t)((s - c.t_in) * 16)), "v"(dead), "s"(c.halo_out) : "memory");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tp_prog_store(c.prog_out, kTpProgDone);
     }
@@ -560,6 +624,9 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
         const __attribute__((address_space(3))) uint32_t *sw = (const __attribute__((address_space(3))) uint32_t *)(uintptr_t)stat_lds;
         TpStats st;
         st.spins = sw[0] | ((unsigned long long)((xcc & 0xf) << 16 | (hw & 0xffff))) << 32;   // where the tile ran: XCC, SE/SH/CU/SIMD/wave slot
+        st.phase[0] = sw[3] | ((unsigned long long)sw[4] << 32);
+        st.phase[1] = sw[5] | ((unsigned long long)sw[6] << 32);
+        st.phase[2] = sw[7];
         st.wait_ticks = sw[1] | ((unsigned long long)sw[2] << 32);   // (high half: shader cycles inside the unguarded frame blocks)
         st.start_tick = __builtin_amdgcn_s_memtime() - stats_out->total_ticks;   // (the tile's shader cycles)
         st.total_ticks = wall_clock64() - stats_out->start_tick;
@@ -567,8 +634,9 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
     }
     // ---- terminal state: the HIGHEST live position of frame T-1 (align.py:99-101), over the tiles alive then ----
     if ((uint32_t)c.t_end == c.T) {
-        tp_masks(c.mk, (int32_t)c.lo - c.base, (int32_t)c.hi - c.base);
-        tp_mask_state(c.S, c.mk, NINF);
+        TpMasks mk;   // (the only full band mask of a tile's life: cells above hi may hold leaked scores)
+        tp_masks(mk, (int32_t)c.lo - c.base, (int32_t)c.hi - c.base);
+        tp_mask_state(c.S, mk, NINF);
         const float cell[4] = {c.S[0], c.S[2], c.S[1], c.S[3]};
         unsigned long long key = 0;
 #pragma unroll
@@ -608,13 +676,13 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
 // so whatever order the dispatcher starts workgroups in, a tile's producer holds an earlier ticket and is running or done
 // - the earliest unfinished ticket can always run to completion.
 constexpr unsigned kTpLdsRequest = 40 * 1024;   // used: 16 KB rows + 1 KB packets + 16 KB publish staging
-template <int M>
+template <int M, int PITCH, bool CONTIG>
 __global__ __launch_bounds__(64) void forward_tp_kernel(const Lattice *__restrict__ lats, const TileTask *__restrict__ tasks, int n_tasks,
                                                         int32_t *meta, char *halo, uint32_t *prog, TileAux *aux, uint32_t *ticket, int verify, TpStats *stats)
 {
     extern __shared__ __attribute__((aligned(16))) char tp_lds[];
     const uint32_t lds_rows = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&tp_lds[0];
-    const uint32_t lds_halo = lds_rows + kTpRing * kTpBlock * kTpRowBytes;
+    const uint32_t lds_halo = lds_rows + kTpRing * kTpSlotBytes;
     uint32_t tix = 0;
     if (threadIdx.x == 0) tix = atomicAdd(ticket, 1u);
     tix = (uint32_t)__builtin_amdgcn_readfirstlane((int)tix);
@@ -623,9 +691,9 @@ __global__ __launch_bounds__(64) void forward_tp_kernel(const Lattice *__restric
     const Lattice &d = lats[__builtin_amdgcn_readfirstlane(tk.lat)];
     const int flags = __builtin_amdgcn_readfirstlane(meta_of(meta, d.idx)[2]);
     if (flags & kFlagZeroLabel)
-        tp_run_tile<M, true>(d, tk, meta, halo, (gu32w_t)prog, aux, lds_rows, lds_halo, verify, stats + tix);
+        tp_run_tile<M, true, PITCH, CONTIG>(d, tk, meta, halo, (gu32w_t)prog, aux, lds_rows, lds_halo, verify, stats + tix);
     else
-        tp_run_tile<M, false>(d, tk, meta, halo, (gu32w_t)prog, aux, lds_rows, lds_halo, verify, stats + tix);
+        tp_run_tile<M, false, PITCH, CONTIG>(d, tk, meta, halo, (gu32w_t)prog, aux, lds_rows, lds_halo, verify, stats + tix);
 }
 
 }  // namespace ka
