@@ -387,8 +387,12 @@ int ka_engine_last_kernel_ms(ka_engine *e, float ms[4])
 
 // The tiled form pays off when the one-wavefront-per-lattice form leaves the chip idle: a lattice costs ~5 concurrently
 // running tile wavefronts (a 1000-wide band touches 4-5 tiles), the chip has 1024 SIMDs.  Measured crossover: DESIGN.md.
-constexpr int32_t kAutoTiledMaxLattices = 160;
-constexpr int32_t kAutoParallelBacktraceMaxLattices = 512;
+// (tools/sweep_auto.py, lattices of 20000 frames: tiled ahead up to 256 lattices - 3.55 vs 4.55 ms forward -, level at 384)
+constexpr int32_t kAutoTiledMaxLattices = 288;
+// The serial backtrace costs ~165 ns per frame of the LONGEST lattice (one wavefront each, side by side), the chunk-parallel
+// one ~0.62 ns per frame of ALL lattices (it is throughput-bound: it recomputes the whole band): parallel while
+// sum(T) < 256 max(T).  (same sweep: level at 256 lattices of equal length)
+constexpr int64_t kAutoParallelBacktraceFrameRatio = 256;
 
 static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, const int64_t *T, int32_t V,
                         const int64_t *ld, const int32_t *const *labels, const int64_t *S, int32_t beam_size,
@@ -442,7 +446,13 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
         int32_t n_ck = 0;   // lattices that end in backtrace_rc
         for (int32_t i = 0; i < n; ++i)
             n_ck += (sh[i].tiled || (sh[i].fast && e->mode != KA_MODE_WORKGROUP && e->mode != KA_MODE_WAVE_EXACT && sh[i].T < (int64_t(1) << 26))) ? 1 : 0;
-        const bool par = e->backtrace == KA_BACKTRACE_PARALLEL || (e->backtrace == KA_BACKTRACE_AUTO && n_ck <= kAutoParallelBacktraceMaxLattices);
+        int64_t sum_T = 0, max_T = 1;
+        for (int32_t i = 0; i < n; ++i) {
+            sum_T += sh[i].T;
+            max_T = std::max<int64_t>(max_T, sh[i].T);
+        }
+        (void)n_ck;
+        const bool par = e->backtrace == KA_BACKTRACE_PARALLEL || (e->backtrace == KA_BACKTRACE_AUTO && sum_T < kAutoParallelBacktraceFrameRatio * max_T);
         for (int32_t i = 0; i < n; ++i)
             sh[i].par_bt = par && (sh[i].tiled || (sh[i].fast && e->mode != KA_MODE_WORKGROUP && e->mode != KA_MODE_WAVE_EXACT));
     }
