@@ -133,3 +133,67 @@ def test_cfg1_gongitsune_full_size(mode):
         _set(eng, "auto")
     del lps, labs
     torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------
+# BASELINE configs[4]: the long-form stress lattice, banded (beam 1000) and as the whole lattice (beam >= 2L, "tiled DP")
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T,S,V", [(8000, 10000, 64), (6000, 6000, 39), (3000, 9000, 20)])
+def test_full_lattice_mode_vs_oracle_reduced_size(T, S, V):
+    """beam_size >= 2L: every position of every frame is in the band (align.py:64-65 degenerates to lo = 0, hi = L).
+    L up to 20001 = 79 tiles alive from the first frame to the last, one wavefront each; bit-exact vs the C oracle."""
+    from kokoro_align_amd import workloads as W
+    from kokoro_align_amd.align import DeviceBatch
+    L = 2 * S + 1
+    lps, labs = W.device_book([(T, S)], V=V, seed0=31)
+    lp = O.hash_logprobs_c(T, V, 31)
+    lab = O.hash_labels(S, V, 31)
+    eng = _engine()
+    for beam in (2 * L, 2 * L + 7):
+        try:
+            want = O.ctc_best_path_c(lp, lab, beam, 4, return_total=True)
+        except ValueError:
+            want = None
+        for mode in ("auto", "tiled+parallel", "tiled"):
+            _set(eng, mode)
+            try:
+                b = DeviceBatch(lps, labs, beam)
+                st = b.run(raise_on_error=False)
+                if want is None:
+                    assert st[0] == -1
+                    continue
+                assert st[0] == 0
+                assert np.array_equal(b.path[0].cpu().numpy(), want[0]), (mode, beam)
+                assert np.array_equal(b.best_labels[0].cpu().numpy(), want[1])
+                assert np.array_equal(b.best_scores[0].cpu().numpy().view(np.int32), want[2].view(np.int32))
+                assert np.float32(b.total[0]).view(np.int32) == np.float32(want[3]).view(np.int32)
+            finally:
+                _set(eng, "auto")
+
+
+@pytest.mark.parametrize("beam", [1000, None])
+def test_cfg5_stress_lattice_at_full_size_properties(beam):
+    """T = 500000 x V = 64, S = 50000 (L = 100001): the banded case (beam 1000) and the whole lattice (beam >= 2L,
+    5e10 cells - the CPU reference would need hours), checked through size-independent properties: monotone path with
+    steps <= 3 that ends on the trailing blank, labels = lab'[path], scores = the emissions, and the float32 chain of
+    the scores along the path equal to the forward pass's best cumulative score bit for bit."""
+    import torch
+    from kokoro_align_amd import workloads as W
+    from kokoro_align_amd.align import DeviceBatch
+    c = W.CFG5
+    T, S, V = c["T"], c["S"], c["V"]
+    L = 2 * S + 1
+    lps, labs = W.device_book([(T, S)], V=V, seed0=5)
+    b = DeviceBatch(lps, labs, beam if beam else 2 * L + 2)
+    _set(_engine(), "auto")
+    b.run()
+    p = b.path[0].cpu().numpy(); l = b.best_labels[0].cpu().numpy(); s = b.best_scores[0].cpu().numpy()
+    ext = np.zeros(L, np.int32); ext[1::2] = labs[0].cpu().numpy()
+    d = np.diff(p)
+    assert (d >= 0).all() and (d <= 3).all() and p[-1] == L - 1 and p[0] in (0, 1, 3)
+    assert np.array_equal(l, ext[p])
+    assert np.array_equal(s, lps[0].cpu().numpy()[np.arange(T), l])
+    chain = np.add.accumulate(s, dtype=np.float32)[-1]
+    assert np.float32(chain).view(np.int32) == np.float32(b.total[0]).view(np.int32)
+    del b, lps, labs
+    torch.cuda.empty_cache()
