@@ -990,6 +990,9 @@ __device__ __forceinline__ void forward_ck(const Lattice &d, int32_t *meta)
     }
 }
 
+#ifndef KA_RC_MIN_WAVES
+#define KA_RC_MIN_WAVES 8
+#endif
 #ifndef KA_FWD_MIN_WAVES
 #define KA_FWD_MIN_WAVES 4
 #endif
@@ -1498,6 +1501,155 @@ __device__ __forceinline__ uint64_t lane_field(uint32_t count, uint32_t first)
     asm("s_bfm_b64 %0, %1, %2" : "=s"(m) : "s"(count), "s"(first));
     return m;
 }
+// One frame of the window recurrence for max_move = 4, written out so that it costs 23 vector instructions (25 where the
+// window touches a band edge) instead of the 29 hipcc makes of the cell_blank / cell_label formulation:
+//   * the three operands that come from the lane below (label pb-1 for both cells, blank pb-2) enter their adds through
+//     DPP (v_add_f32_dpp .. wave_ror:1) instead of through a v_mov_dpp each, and the blank cell's move-3 candidate
+//     score(pb-3) + e0 is the move-1 candidate score(pb-1) + e0 of the lane below - e0 is the same in every lane - so it
+//     is one more rotation of a sum that exists already: the same float add on the same operands, in another lane;
+//   * DPP takes no scalar operand, so the blank emission lp[t, 0] is fetched into a VGPR with a second ds_bpermute
+//     (address 0) next to the label emission's; both are issued one frame ahead and waited for at the end of the block;
+//   * `open` (the cells the walk can reach lie inside the band at every frame of the chunk, the usual case): the band
+//     select is branched over on the scalar unit - the maxima stay in sb / sl as they are.
+// Software hazards the assembler does not see to (DPP reads a VGPR written by the previous VALU instruction: 2 wait
+// states): sb / sl are last written by the selects, with the s_waitcnt and the next block's two ds_bpermute between them
+// and the next DPP read; t1 is written 6 instructions before its DPP read.
+// `word` takes 4 code bits per frame exactly as cell_blank<4> / cell_label<4> would shift them in.
+#ifndef KA_RC_DIAG
+#define KA_RC_DIAG 0
+#endif
+#ifndef KA_RC_WALK_GATHERS
+#define KA_RC_WALK_GATHERS 1
+#endif
+#ifndef KA_RC_E0_SCALAR
+#define KA_RC_E0_SCALAR 1
+#endif
+#if KA_RC_E0_SCALAR
+// the blank emission as a scalar (v_readfirstlane): one LDS-pipe instruction less per frame - that pipe is shared by
+// the CU's four SIMDs and a ds_bpermute holds it for 7 cycles (tools/ubench/lds_rates.hip) - for one more DPP move:
+// DPP takes no scalar operand, so score(pb-1) + e0 is formed as ror(sl + e0).
+#define KA_RC_E0_OUT "=&s"
+#define KA_RC_E0_IN "s"
+#if KA_RC_DIAG == 2   // (timing experiment, results wrong: no emission gathers)
+#define KA_RC_GATHER "v_mov_b32 %[eln], %[rown]\n\tv_readfirstlane_b32 %[e0n], %[rown]\n\t"
+#else
+#define KA_RC_GATHER "ds_bpermute_b32 %[eln], %[lab4], %[rown]\n\tv_readfirstlane_b32 %[e0n], %[rown]\n\t"
+#endif
+#define KA_RC_HEAD                                                                        \
+    KA_RC_GATHER                                                                          \
+    "v_add_f32 %[t2], %[e0], %[sl]\n\t"                                                   \
+    "v_add_f32_dpp %[t4], %[sl], %[el] wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"         \
+    "v_add_f32_dpp %[t5], %[sb], %[el] wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"         \
+    "v_add_f32 %[t0], %[e0], %[sb]\n\t"                                                   \
+    "v_add_f32 %[t3], %[sb], %[el]\n\t"                                                   \
+    "v_add_f32 %[t7], %[sl], %[el]\n\t"                                                   \
+    "v_mov_b32_dpp %[t1], %[t2] wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"                \
+    "v_max_f32 %[t6], %[t7], %[t3]\n\t"
+#define KA_RC_VETO "v_min_f32 %[t4], %[t4], %[veto]\n\t"
+// (two instructions between the write of t1 and its DPP read)
+#define KA_RC_MAX                                                                         \
+    "v_max3_f32 %[sl], %[t6], %[t4], %[t5]\n\t"                                           \
+    "s_nop 0\n\t"                                                                         \
+    "v_mov_b32_dpp %[t2], %[t1] wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"                \
+    "v_max3_f32 %[sb], %[t0], %[t1], %[t2]\n\t"
+#else
+#define KA_RC_E0_OUT "=&v"
+#define KA_RC_E0_IN "v"
+#if KA_RC_DIAG == 2   // (timing experiment, results wrong: no emission gathers)
+#define KA_RC_GATHER "v_mov_b32 %[eln], %[rown]\n\tv_mov_b32 %[e0n], %[rown]\n\t"
+#else
+#define KA_RC_GATHER "ds_bpermute_b32 %[eln], %[lab4], %[rown]\n\tds_bpermute_b32 %[e0n], %[zero], %[rown]\n\t"
+#endif
+#define KA_RC_HEAD                                                                        \
+    KA_RC_GATHER                                                                          \
+    "v_add_f32_dpp %[t1], %[sl], %[e0] wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"         \
+    "v_add_f32_dpp %[t4], %[sl], %[el] wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"         \
+    "v_add_f32_dpp %[t5], %[sb], %[el] wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"         \
+    "v_add_f32 %[t0], %[sb], %[e0]\n\t"                                                   \
+    "v_add_f32 %[t3], %[sb], %[el]\n\t"                                                   \
+    "v_add_f32 %[t7], %[sl], %[el]\n\t"
+#define KA_RC_VETO "v_min_f32 %[t4], %[t4], %[veto]\n\t"
+#define KA_RC_MAX                                                                         \
+    "v_mov_b32_dpp %[t2], %[t1] wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"                \
+    "v_max_f32 %[t6], %[t7], %[t3]\n\t"                                                   \
+    "v_max3_f32 %[sl], %[t6], %[t4], %[t5]\n\t"                                           \
+    "v_max3_f32 %[sb], %[t0], %[t1], %[t2]\n\t"
+#endif
+#if KA_RC_DIAG == 3   // (timing experiment, results wrong: no back-pointer codes)
+#define KA_RC_CODES_X ""
+#else
+#define KA_RC_CODES_X KA_RC_CODES
+#endif
+#if KA_RC_DIAG == 7   // (timing experiment, results wrong: the label cell's compare masks are not combined)
+#define KA_RC_COMBINE                                                                     \
+    "v_addc_co_u32 %[w], %[sy], %[w], %[w], %[sb2]\n\t"                                   \
+    "v_addc_co_u32 %[w], %[sx], %[w], %[w], %[sc]\n\t"
+#else
+#define KA_RC_COMBINE                                                                     \
+    "s_or_b64 %[sx], %[sa], %[sb2]\n\t"                                                   \
+    "v_addc_co_u32 %[w], %[sy], %[w], %[w], %[sx]\n\t"                                    \
+    "s_andn2_b64 %[sc], %[sc], %[sb2]\n\t"                                                \
+    "s_or_b64 %[sc], %[sc], %[sa]\n\t"                                                    \
+    "v_addc_co_u32 %[w], %[sy], %[w], %[w], %[sc]\n\t"
+#endif
+#define KA_RC_CODES                                                                       \
+    "v_cmp_eq_f32 %[sa], %[t0], %[sb]\n\t"                                                \
+    "v_addc_co_u32 %[w], %[sy], %[w], %[w], %[sa]\n\t"                                    \
+    "v_cmp_eq_f32 %[sa], %[t1], %[sb]\n\t"                                                \
+    "v_addc_co_u32 %[w], %[sy], %[w], %[w], %[sa]\n\t"                                    \
+    "v_cmp_eq_f32 %[sa], %[t7], %[sl]\n\t"                                                \
+    "v_cmp_eq_f32 %[sb2], %[t3], %[sl]\n\t"                                               \
+    "v_cmp_eq_f32 %[sc], %[t4], %[sl]\n\t"                                                \
+    KA_RC_COMBINE
+// band select, skipped by a scalar branch inside the block when the chunk is open (a branch around two asm blocks made
+// hipcc allocate the loop-carried registers differently on the two sides and reconcile them with three v_mov per frame)
+#if KA_RC_DIAG == 9   // (timing experiment: eight idle instructions, 32 bytes, per frame)
+#define KA_RC_PAD "s_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\t"
+#elif KA_RC_DIAG == 10   // (timing experiment: four idle vector instructions of 8 bytes per frame)
+#define KA_RC_PAD "v_max3_f32 %[t6], %[t6], %[t6], %[t6]\n\tv_max3_f32 %[t5], %[t5], %[t5], %[t5]\n\tv_max3_f32 %[t6], %[t6], %[t6], %[t6]\n\tv_max3_f32 %[t5], %[t5], %[t5], %[t5]\n\t"
+#else
+#define KA_RC_PAD ""
+#endif
+#define KA_RC_BAND                                                                        \
+    KA_RC_PAD                                                                             \
+    "s_bitcmp1_b32 %[open], 0\n\t"                                                        \
+    "s_cbranch_scc1 .Lka_rc_open_%=\n\t"                                                  \
+    "v_cndmask_b32 %[sb], %[ninf], %[sb], %[mb]\n\t"                                      \
+    "v_cndmask_b32 %[sl], %[ninf], %[sl], %[ml]\n"                                        \
+    ".Lka_rc_open_%=:\n\t"                                                                \
+    "s_waitcnt lgkmcnt(0)"
+#define KA_RC_OUTS                                                                                                              \
+    [sb] "+v"(sb), [sl] "+v"(sl), [w] "+v"(word), [eln] "=&v"(el_next), [e0n] KA_RC_E0_OUT(e0_next), [t0] "=&v"(t0), [t1] "=&v"(t1),   \
+    [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7), [sa] "=&s"(sa),             \
+    [sb2] "=&s"(sb2), [sc] "=&s"(sc), [sx] "=&s"(sx), [sy] "=&s"(sy)
+#define KA_RC_INS                                                                                                               \
+    [e0] KA_RC_E0_IN(e0), [el] "v"(el), [rown] "v"(row_next), [lab4] "v"(lab4), [zero] "v"(zero), [open] "s"(open), [mb] "s"(mask_b),   \
+    [ml] "s"(mask_l), [ninf] "v"(NINF)
+template <bool ZL>
+__device__ __forceinline__ void rc_frame4(float &sb, float &sl, uint32_t &word, float e0, float el, float &e0_next, float &el_next,
+                                          float row_next, int lab4, int zero, float veto, uint32_t open, uint64_t mask_b,
+                                          uint64_t mask_l, float NINF)
+{
+    float t0, t1, t2, t3, t4, t5, t6, t7;
+    uint64_t sa, sb2, sc, sx, sy;
+    if constexpr (ZL)
+        asm volatile(KA_RC_HEAD KA_RC_VETO KA_RC_MAX KA_RC_CODES_X KA_RC_BAND : KA_RC_OUTS : KA_RC_INS, [veto] "v"(veto) : "memory", "scc");
+    else
+        asm volatile(KA_RC_HEAD KA_RC_MAX KA_RC_CODES_X KA_RC_BAND : KA_RC_OUTS : KA_RC_INS : "memory", "scc");
+}
+#undef KA_RC_HEAD
+#undef KA_RC_GATHER
+#undef KA_RC_E0_OUT
+#undef KA_RC_E0_IN
+#undef KA_RC_CODES_X
+#undef KA_RC_VETO
+#undef KA_RC_MAX
+#undef KA_RC_CODES
+#undef KA_RC_COMBINE
+#undef KA_RC_BAND
+#undef KA_RC_PAD
+#undef KA_RC_OUTS
+#undef KA_RC_INS
 constexpr int kRcLanes = 62;   // lanes 62 and 63 are kept at -inf: they are the "nothing below position 0" that
                                // wave_ror hands to lanes 0 and 1 (window width 124 >= 97 + slack)
 
@@ -1514,11 +1666,53 @@ __device__ __forceinline__ int lattice_of_chunk(const Lattice *__restrict__ lats
 }
 __device__ __forceinline__ int chunks_of(int T) { return (T - 1) / kCkFrames + 1; }
 
+// The walk over one chunk's codes (4 bits per lane and frame, frame f in nibble 7 - f%8 of codes[f/8]; per nibble
+// [blank hi, blank lo, label hi, label lo], every cell coded 3 - move): pathv[lane f] = position of frame f relative to
+// the window.  One scalar chain per frame: v_readlane -> shift -> 3 & ~code -> subtract.  FULL: all 32 frames, straight
+// line (the `f < n` test of the last, partial chunk costs a compare and a taken branch per frame).
+template <bool FULL>
+__device__ __forceinline__ void rc_walk(const uint32_t (&codes)[kCkFrames / 8], int n, int &qq, int &pathv)
+{
+#pragma unroll
+    for (int f = kCkFrames - 1; f >= 0; --f) {
+        if (FULL || f < n) {
+            const int sh = 4 * (7 - (f & 7)) + ((qq & 1) ? 0 : 2);
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)codes[f >> 3], qq >> 1) >> sh;
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(pathv) : "s"(qq), "i"(f));
+            qq -= bp_decode(w);
+        }
+    }
+}
+// The same walk, also collecting best_labels / best_scores (align.py:105-107) on the way: the label of the path's cell
+// comes out of the window's label register (lane j: 4 * label of position wlo+2j+1; a blank cell: label 0) and the score
+// out of the frame's row register (lane v = lp[t0+f, v]), both with v_readlane at a scalar lane index - two vector
+// instructions more per frame than gathering the scores afterwards with a ds_bpermute per frame, but the LDS pipe, which
+// the CU's four SIMDs share and the frame loop's emission gather needs, is left alone.
+template <bool FULL>
+__device__ __forceinline__ void rc_walk_out(const uint32_t (&codes)[kCkFrames / 8], const float (&rows)[kCkFrames], int lab4, int n,
+                                            int &qq, int &pathv, int &labv, float &scv)
+{
+#pragma unroll
+    for (int f = kCkFrames - 1; f >= 0; --f) {
+        if (FULL || f < n) {
+            const int j = qq >> 1;
+            const int sh = 4 * (7 - (f & 7)) + ((qq & 1) ? 0 : 2);
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)codes[f >> 3], j) >> sh;
+            const int col = (qq & 1) ? __builtin_amdgcn_readlane(lab4, j) >> 2 : 0;
+            const int sc = __builtin_amdgcn_readlane(__builtin_bit_cast(int, rows[f]), col);
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(pathv) : "s"(qq), "i"(f));
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(labv) : "s"(col), "i"(f));
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(scv) : "s"(sc), "i"(f));
+            qq -= bp_decode(w);
+        }
+    }
+}
+
 // PAR = false: one wavefront per lattice walks its chunks from the last to the first (the position a chunk is entered
 // at comes out of the chunk above it).  PAR = true: one wavefront per CHUNK, entered at Lattice::entry[chunk], which the
 // chunk-parallel backtrace (ka_parallel_bt.hpp) has worked out for every chunk beforehand; grid = all chunks of the launch.
 template <int M, bool ZL, bool PAR>
-__global__ __launch_bounds__(64) void backtrace_rc_kernel(const Lattice *__restrict__ lats, const int32_t *meta, int n_lats)
+__global__ __launch_bounds__(64, KA_RC_MIN_WAVES) void backtrace_rc_kernel(const Lattice *__restrict__ lats, const int32_t *meta, int n_lats)
 {
     const int which = PAR ? __builtin_amdgcn_readfirstlane(lattice_of_chunk(lats, n_lats, (int64_t)blockIdx.x)) : (int)blockIdx.x;
     const Lattice &d = lats[which];
@@ -1580,7 +1774,11 @@ __global__ __launch_bounds__(64) void backtrace_rc_kernel(const Lattice *__restr
             if (n == kCkFrames) {
 #pragma unroll
                 for (int f = 0; f < kCkFrames; ++f) {
+#if KA_RC_DIAG == 1   // (timing experiment, results wrong: no log-prob rows from memory)
+                    rows[f] = -1.0f - (float)f;
+#else
                     rows[f] = row_load(col_off, rp);
+#endif
                     rp += ldb;
                 }
             } else {
@@ -1607,7 +1805,7 @@ __global__ __launch_bounds__(64) void backtrace_rc_kernel(const Lattice *__restr
             sl = ((uint32_t)pb + 1 >= lo1 && (uint32_t)pb + 1 < hi1 && lane < kRcLanes) ? ckv.y : NINF;
         }
         // ---- forward over the chunk: scores + back-pointer codes of the window ----
-        uint32_t codes[kCkFrames / 8];
+        uint32_t codes[kCkFrames / 8] = {};
         // floor(L*(t0+f)/T) of all frames of the chunk at once, lane f <-> frame f (r0 + 33*dr < 34*T: the host
         // keeps T below 2^26 in this form), and the frames after which it moves as a bit mask: the common frame
         // then pays one s_bitcmp1 + s_cbranch for the band instead of a scalar Bresenham step
@@ -1621,74 +1819,158 @@ __global__ __launch_bounds__(64) void backtrace_rc_kernel(const Lattice *__restr
         };
         const uint32_t qnum = r0 + (uint32_t)lane * dr;
         const uint32_t qa = q0 + (uint32_t)lane * dq + div_T(qnum);
-        const uint32_t qb = q0 + (uint32_t)(lane + 1) * dq + div_T(qnum + dr);
-        const uint32_t moves = (uint32_t)__builtin_amdgcn_ballot_w64(qa != qb);   // bit f: frame f+1's band differs from frame f's
+        // band of frame t0+f, relative to the window and clamped to the 2*kRcLanes cells that are computed, as two lane
+        // masks: blank wlo+2l in band <=> l in [ceil(x/2), ceil(y/2));  label wlo+2l+1 <=> l in [floor(x/2), floor(y/2))
         uint64_t mask_b = 0, mask_l = 0;
-#pragma unroll
-        for (int f = 0; f < kCkFrames; ++f) {
-            if (f == 0 || ((moves >> (f > 0 ? f - 1 : 0)) & 1u)) {
-                const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)qa, f);
-                const int32_t dl = (int32_t)q - (int32_t)halfB;
-                const int32_t lo = dl > 0 ? dl : 0;
-                const int32_t hi = (L - (uint32_t)lo < B) ? (int32_t)L : lo + (int32_t)B;
-                // window-relative band [x, y), clamped to the 2*kRcLanes cells that are computed.
-                // blank wlo+2l in band <=> l in [ceil(x/2), ceil(y/2));  label wlo+2l+1 <=> l in [floor(x/2), floor(y/2))
-                int32_t x = lo - wlo, y = hi - wlo;
-                x = x < 0 ? 0 : x;
-                y = y < 0 ? 0 : y;
-                asm("" : "+s"(x), "+s"(y));   // (keeps the clamp on the scalar unit: no v_med3)
-                x = x > 2 * kRcLanes ? 2 * kRcLanes : x;
-                y = y > 2 * kRcLanes ? 2 * kRcLanes : y;
-                const uint32_t xb = (uint32_t)(x + 1) >> 1, yb = (uint32_t)(y + 1) >> 1, xl = (uint32_t)x >> 1, yl = (uint32_t)y >> 1;
-                mask_b = lane_field(yb - xb, xb);
-                mask_l = lane_field(yl - xl, xl);
+        const auto band_masks = [&](int f) {
+            const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)qa, f);
+            const int32_t dl = (int32_t)q - (int32_t)halfB;
+            const int32_t lo = dl > 0 ? dl : 0;
+            const int32_t hi = (L - (uint32_t)lo < B) ? (int32_t)L : lo + (int32_t)B;
+            int32_t x = lo - wlo, y = hi - wlo;
+            x = x < 0 ? 0 : x;
+            y = y < 0 ? 0 : y;
+            asm("" : "+s"(x), "+s"(y));   // (keeps the clamp on the scalar unit: no v_med3)
+            x = x > 2 * kRcLanes ? 2 * kRcLanes : x;
+            y = y > 2 * kRcLanes ? 2 * kRcLanes : y;
+            const uint32_t xb = (uint32_t)(x + 1) >> 1, yb = (uint32_t)(y + 1) >> 1, xl = (uint32_t)x >> 1, yl = (uint32_t)y >> 1;
+            mask_b = lane_field(yb - xb, xb);
+            mask_l = lane_field(yl - xl, xl);
+        };
+        if constexpr (M == 4) {
+            // Does the band cut into the cells the walk can reach, [wlo, p], at any frame t0-1 .. t0+31?  The band only
+            // moves up: it does not iff its low edge at the last frame is at or below wlo and its high edge at frame t0-1
+            // is above p.  Then nothing is masked (rc_frame4<.., false>): cells of the window above p may lie outside the
+            // band and hold anything, as may the ring slots they were loaded from - nothing the walk reads depends on a
+            // cell above itself.  (Same argument as for the window's low edge, see the head of this section.)
+            bool open = false;
+            if (t0 != 0 && n == kCkFrames) {
+                const uint32_t q_last = (uint32_t)__builtin_amdgcn_readlane((int)qa, kCkFrames - 1);
+                const int32_t dl_last = (int32_t)q_last - (int32_t)halfB;
+                const uint32_t qm = r0 >= dr ? q0 - dq : q0 - dq - 1;
+                const int32_t dl = (int32_t)qm - (int32_t)halfB;
+                const uint32_t lo1 = (uint32_t)(dl > 0 ? dl : 0);
+                const uint32_t hi1 = (L - lo1 < B) ? L : lo1 + B;
+                // (wlo == 0: the cells below the window do not exist and count as -inf, which only the masked form's idle
+                //  lanes 62 and 63 hand to lanes 0 and 1)
+                open = wlo > 0 && dl_last <= wlo && (uint32_t)p < hi1;
             }
-            row_wait_n(rows[f], kCkFrames - 1 - f);
-            const float el = bperm(lab4, rows[f]);
-            const float e0 = first_lane(rows[f]);
-            const float L1 = wave_ror1(sl);    // score of pb-1 (lane 0: lane 63's, always -inf)
-            const float B1 = wave_ror1(sb);    // score of pb-2
-            const float L2 = wave_ror1(L1);    // score of pb-3 (lanes 0, 1: lanes 62, 63's, always -inf)
-            uint32_t &word = codes[f >> 3];
-            if ((f & 7) == 0) word = 0;
-            float mb, ml;
-            cell_blank<M>(sb, L1, L2, e0, mb, word);
-            cell_label<M, ZL>(sl, sb, L1, B1, el, veto, ml, word);
-            sb = select_by_mask(NINF, mb, mask_b);
-            sl = select_by_mask(NINF, ml, mask_l);
+            const int zero = 0;
+            float e0c, elc, e0n, eln;
+            row_wait_n(rows[0], kCkFrames - 1);
+#if KA_RC_E0_SCALAR
+            asm volatile("ds_bpermute_b32 %0, %2, %4\n\t"
+                         "v_readfirstlane_b32 %1, %4\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(elc), "=&s"(e0c) : "v"(lab4), "v"(zero), "v"(rows[0]) : "memory");
+#else
+            asm volatile("ds_bpermute_b32 %0, %2, %4\n\t"
+                         "ds_bpermute_b32 %1, %3, %4\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(elc), "=&v"(e0c) : "v"(lab4), "v"(zero), "v"(rows[0]) : "memory");
+#endif
+            // the frames after which floor(L*t/T) moves, as a bit mask: the common frame then pays one s_bitcmp1 +
+            // s_cbranch for the band instead of a scalar Bresenham step
+            uint32_t moves = 0;
+            const uint32_t open_bit = (uint32_t)__builtin_amdgcn_readfirstlane(open ? 1 : 0);
+            if (open_bit) {
+                sb = ckv.x;
+                sl = ckv.y;
+            } else {
+                const uint32_t qb = q0 + (uint32_t)(lane + 1) * dq + div_T(qnum + dr);
+                moves = (uint32_t)__builtin_amdgcn_ballot_w64(qa != qb) << 1 | 1u;   // bit f: frame f's band differs from frame f-1's (bit 0: set it up)
+            }
+            asm volatile("s_nop 1" : "+v"(sb), "+v"(sl));   // (a DPP read follows within the next block)
+            // ONE loop for both kinds of chunk: the row registers are waited for in one place per frame whichever way the
+            // chunk goes (two loops made hipcc copy rows whose loads were in flight)
+#pragma unroll
+            for (int f = 0; f < kCkFrames; ++f) {
+                if ((moves >> f) & 1u) band_masks(f);
+                if (f + 1 < kCkFrames) row_wait_n(rows[f + 1], kCkFrames - 2 - f);
+                rc_frame4<ZL>(sb, sl, codes[f >> 3], e0c, elc, e0n, eln, rows[f + 1 < kCkFrames ? f + 1 : f], lab4, zero, veto,
+                              open_bit, mask_b, mask_l, NINF);
+                e0c = e0n;
+                elc = eln;
+            }
+        } else {
+            const uint32_t qb = q0 + (uint32_t)(lane + 1) * dq + div_T(qnum + dr);
+            const uint32_t moves = (uint32_t)__builtin_amdgcn_ballot_w64(qa != qb);
+#pragma unroll
+            for (int f = 0; f < kCkFrames; ++f) {
+                if (f == 0 || ((moves >> (f > 0 ? f - 1 : 0)) & 1u)) band_masks(f);
+                row_wait_n(rows[f], kCkFrames - 1 - f);
+                const float el = bperm(lab4, rows[f]);
+                const float e0 = first_lane(rows[f]);
+                const float L1 = wave_ror1(sl);    // score of pb-1 (lane 0: lane 63's, always -inf)
+                const float B1 = wave_ror1(sb);    // score of pb-2
+                const float L2 = wave_ror1(L1);    // score of pb-3 (lanes 0, 1: lanes 62, 63's, always -inf)
+                uint32_t &word = codes[f >> 3];
+                if ((f & 7) == 0) word = 0;
+                float mb, ml;
+                cell_blank<M>(sb, L1, L2, e0, mb, word);
+                cell_label<M, ZL>(sl, sb, L1, B1, el, veto, ml, word);
+                sb = select_by_mask(NINF, mb, mask_b);
+                sl = select_by_mask(NINF, ml, mask_l);
+            }
         }
+#if KA_RC_DIAG == 4   // (timing experiment, results wrong: no walk, no outputs)
+        int qq = p - wlo - (p > 3000 ? 6 : 0);
+        if (lane == 70) path[t0] = (int)codes[0] + (int)codes[3];
+#else
         // ---- walk back over the chunk: pathv[lane f] = position of frame t0+f, relative to wlo ----
 #pragma unroll
         for (int g = 0; g < kCkFrames / 8; ++g) codes[g] = rc_blank_to_uniform(codes[g]);
         int pathv = 0;
         int qq = p - wlo;
-#pragma unroll
-        for (int f = kCkFrames - 1; f >= 0; --f) {
-            if (f < n) {
-                const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)codes[f >> 3], qq >> 1) >> (4 * (7 - (f & 7)));
-                asm("v_writelane_b32 %0, %1, %2" : "+v"(pathv) : "s"(qq), "i"(f));
-                qq -= bp_decode((qq & 1) ? w : (w >> 2));
-            }
+#if KA_RC_WALK_GATHERS
+        // best_path, best_labels = lab'[best_path], best_scores[t] = lp[t, best_labels[t]] (align.py:105-107), lane f
+        // does frame t0+f: collected by the walk itself (rc_walk_out)
+        int labv = 0;
+        float scv = 0.0f;
+        if (n == kCkFrames)
+            rc_walk_out<true>(codes, rows, lab4, n, qq, pathv, labv, scv);
+        else
+            rc_walk_out<false>(codes, rows, lab4, n, qq, pathv, labv, scv);
+        if (lane < n) {
+            path[t0 + lane] = pathv + wlo;
+            lab_out[t0 + lane] = labv;
+            sc_out[t0 + lane] = scv;
         }
+#else
+#if KA_RC_DIAG == 5   // (timing experiment, results wrong: no walk)
+        pathv = (qq - (31 - lane) / 6) & 127;
+        qq -= p > 3000 ? 6 : 0;
+        if (lane == 70) path[t0] = (int)codes[0] + (int)codes[3];
+#else
+        if (n == kCkFrames)
+            rc_walk<true>(codes, n, qq, pathv);
+        else
+            rc_walk<false>(codes, n, qq, pathv);
+#endif
         // best_path, best_labels = lab'[best_path], best_scores[t] = lp[t, best_labels[t]] (align.py:105-107):
         // lane f does frame t0+f.  The score comes from the row registers (lane v of rows[f] = lp[t0+f, v]): a
         // gather from memory would fetch a 128-byte line per frame again (measured: +57 GB per batch, and
         // this kernel runs at HBM speed).  Frame f: every lane looks up its own column in row f, lane f keeps it.
         {
             const int pos = pathv + wlo;
-            const int l4 = (lane < n && (pos & 1)) ? labx[pos >> 1] : 0;   // 4 * label = byte address of the column
+            // 4 * label = byte address of the column: the window's labels are in registers (lane j: position wlo+2j+1)
+            const int lw = __builtin_amdgcn_ds_bpermute((pathv >> 1) * 4, lab4);
+            const int l4 = (lane < n && (pos & 1)) ? lw : 0;
             float sv = 0.0f;
+#if KA_RC_DIAG != 6   // (6: timing experiment, results wrong: no score gather)
 #pragma unroll
             for (int f = 0; f < kCkFrames; ++f) {
-                const int got = __builtin_amdgcn_readlane(__builtin_bit_cast(int, bperm(l4, rows[f])), f);
-                asm("v_writelane_b32 %0, %1, %2" : "+v"(sv) : "s"(got), "i"(f));
+                sv = select_by_mask(sv, bperm(l4, rows[f]), 1ull << f);   // lane f keeps its column of row f
             }
+#endif
             if (lane < n) {
                 path[t0 + lane] = pos;
                 lab_out[t0 + lane] = l4 >> 2;
                 sc_out[t0 + lane] = sv;
             }
         }
+#endif
+#endif
         p = qq + wlo;
         if (PAR || t0 == 0) break;
         t0 -= kCkFrames;

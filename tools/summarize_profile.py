@@ -17,6 +17,7 @@ import shutil
 import sys
 
 src, tag, lattices = sys.argv[1], sys.argv[2], int(sys.argv[3])
+frames_per_lattice = int(sys.argv[4]) if len(sys.argv) > 4 else 50000
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_dir = os.path.join(root, "profiles")
 os.makedirs(out_dir, exist_ok=True)
@@ -58,6 +59,20 @@ rows = []
 for (k, g), c in sorted(pmc.items()):
     rows.append({"kernel": k, "grid_threads": g, "counters_per_dispatch": {n: sum(v) / len(v) for n, v in c.items()}})
 summary["pmc"] = rows
+# the few-lattice forms, one cfg2 lattice per launch
+single = {}
+for name in ("pmc_fetch_single", "pmc_write_single"):
+    f = one(f"{name}/*/*counter_collection.csv")
+    if not f:
+        continue
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        single.setdefault((k, int(r["Grid_Size"])), collections.defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
+summary["pmc_one_lattice"] = [
+    {"kernel": k, "grid_threads": g, "counters_per_dispatch": {n: sum(v) / len(v) for n, v in c.items()},
+     "hbm_bytes": (sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"]) * 2048 if "FETCH_SIZE" in c else 0)
+                  + (sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"]) * 1024 if "WRITE_SIZE" in c else 0)}
+    for (k, g), c in sorted(single.items())]
 # HBM traffic of the dominant (forward) kernel's batch launch: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950
 # FETCH_SIZE reports half of a coalesced streaming read (MI355X_MICROARCH.md §HBM) -> x2.
 for r in rows:
@@ -67,9 +82,23 @@ for r in rows:
             read_b = c["FETCH_SIZE"] * 1024 * 2
             write_b = c["WRITE_SIZE"] * 1024
             summary["forward_hbm_bytes_per_launch"] = {"read_corrected_x2": read_b, "write": write_b, "total": read_b + write_b}
+            # whole step: every kernel of the batch launch (forward, backtrace, gather), same correction
+            job = 0.0
+            for q in rows:
+                if q["grid_threads"] >= lattices:
+                    cc = q["counters_per_dispatch"]
+                    job += cc.get("FETCH_SIZE", 0.0) * 2048 + cc.get("WRITE_SIZE", 0.0) * 1024
+            frames = lattices * frames_per_lattice
+            valu = c.get("SQ_INSTS_VALU")
+            summary["job_hbm_bytes_per_step"] = job
+            summary["forward_valu_per_frame"] = valu / frames if valu else None
             with open(os.path.join(out_dir, "pmc_traffic.json"), "wt") as f:
                 json.dump({"lattices": lattices, "hbm_bytes_per_launch": read_b + write_b, "tag": tag,
-                           "note": "FETCH_SIZE*1024*2 + WRITE_SIZE*1024 of forward_ck_kernel<4,false>, one launch"}, f)
+                           "job_hbm_bytes_per_step": job,
+                           "forward_valu_per_frame": valu / frames if valu else None,
+                           "note": "FETCH_SIZE*1024*2 + WRITE_SIZE*1024 of forward_ck_kernel<4,false>, one launch; "
+                                   "job = the same sum over the step's forward, backtrace and gather launches; "
+                                   "forward_valu_per_frame = SQ_INSTS_VALU of the forward launch / frames"}, f)
 bj = os.path.join(src, "bench_under_rocprof.json")
 if os.path.exists(bj):
     try:
