@@ -128,15 +128,8 @@ __device__ __forceinline__ void tp_halo_store(const void *block_base /* uniform 
     // may have structured the surrounding control flow with lanes parked).  A store wider than 64 bits reads its data
     // registers for two more wait states: the EXEC restore and the s_nop are those.
     uint64_t saved;
-#if defined(KA_TP_EXP) && KA_TP_EXP == 1   // timing experiment only (results wrong across XCDs): plain stores
-    asm volatile("s_nop 4\n\ts_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %4\n\tglobal_store_dwordx4 %1, %2, %3 offset:%5\n\ts_mov_b64 exec, %0\n\ts_nop 0"
-                 : "=&s"(saved) : "v"(0u), "v"(pk), "s"(block_base), "s"(lane_mask), "i"(OFF) : "memory", "scc");
-#elif defined(KA_TP_EXP) && KA_TP_EXP == 2   // timing experiment only: no halo stores at all
-    (void)saved;
-#else
     asm volatile("s_nop 4\n\ts_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %4\n\tglobal_store_dwordx4 %1, %2, %3 offset:%5 sc1\n\ts_mov_b64 exec, %0\n\ts_nop 0"
                  : "=&s"(saved) : "v"(0u), "v"(pk), "s"(block_base), "s"(lane_mask), "i"(OFF) : "memory", "scc");
-#endif
 }
 __device__ __forceinline__ void tp_prog_store(gu32w_t word /* uniform */, uint32_t value)
 {
@@ -229,21 +222,9 @@ __device__ __forceinline__ void tp_frame(TpTile<M, ZL> &c, uint32_t t, float (&H
     const bool live = !GUARDED || ((int32_t)t >= c.t_in && (int32_t)t < c.t_end);
     // LDS reads of frame t+2 (skipped frames read too: they prime the pipeline)
     TpIn far;
-#if defined(KA_TP_EXP) && KA_TP_EXP == 3   // timing experiment only (results wrong): no LDS reads in the frame
-    far.E = f32x2{-1.0f, -2.0f};
-    far.e0 = -1.5f;
-    far.hp = f32x4{NINF, NINF, NINF, NINF};
-    (void)r2_l0; (void)r2_l1; (void)r2_0; (void)h2;
-#elif defined(KA_TP_EXP) && KA_TP_EXP == 4   // timing experiment only: emissions read, the packet not
-    far.E = f32x2{lds_f32(r2_l0), lds_f32(r2_l1)};
-    far.e0 = lds_f32(r2_0);
-    far.hp = f32x4{NINF, NINF, NINF, NINF};
-    (void)h2;
-#else
     far.E = f32x2{lds_f32(r2_l0), lds_f32(r2_l1)};
     far.e0 = lds_f32(r2_0);
     far.hp = lds_f32x4(h2);
-#endif
     if (live) {
         const float b0 = c.S[0], b1 = c.S[1], l0 = c.S[2], l1 = c.S[3];
         f32x2 ml, mb;
@@ -300,9 +281,7 @@ __device__ __forceinline__ void tp_frame(TpTile<M, ZL> &c, uint32_t t, float (&H
     // publish the state after frame t = slot t+1 of the upper boundary (lane 63's four cells)
     // (staged: every lane drops its four cells into this frame's 1-KB row of the LDS staging area - no EXEC change and
     //  no vector-memory instruction per frame; lane 63's go out at the end of the block, tp_publish_block)
-#if !(defined(KA_TP_EXP) && KA_TP_EXP == 5)   // (5: timing experiment only, nothing staged)
     if (live) *(__attribute__((address_space(3))) f32x4 *)(uintptr_t)(c.lds_stage + F * 1024) = c.S;
-#endif
     cur = nxt;
     nxt = far;
 }
