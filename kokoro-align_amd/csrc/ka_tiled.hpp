@@ -15,11 +15,12 @@
 //     1024 single-wave workgroups land on 1024 SIMDs), the rest of the grid waits in the dispatcher.  Tiles are drawn from a
 //     ticket counter; the host sorts tasks by t_in, so a tile's producer always holds an earlier ticket.
 //   * Hand-off (cdna_hip_programming.md Guideline 16, sc1 payload + drained + sc1 flag; all loads of it sc1): halo packets
-//     are write-through stores of one lane; a tile publishes "slots < n are complete" once per 16-frame block, n being what
+//     are write-through stores of one lane; a tile publishes "slots < n are complete" once per 32-frame block, n being what
 //     its in-order vmcnt wait has already retired - the publish never waits for anything; the consumer polls that word
 //     once per block, two blocks ahead of use.  Every slot is written once and read once: no ring, no back-pressure.
-//   * Log-prob rows and halo packets are staged through LDS in blocks of 16 frames (loaded one block, written to LDS the
-//     next, consumed the one after: >= 16 frames of latency cover), so the frame loop reads only LDS.
+//   * Log-prob rows and halo packets are staged through LDS in blocks of 32 frames (LDS-DMA, requested three blocks ahead of
+//     their use), so the frame loop reads only LDS.  (Blocks of 16 frames: the per-block work - poll, DMA requests,
+//     publish, finiteness sum - was as long as the block's frames; 32: 93 -> 70 ns per frame of a lone tile.)
 //   * Scores only, like forward_ck: the score ring is stored every 32 frames (position p at slot p & ck_mask of its
 //     checkpoint row) and backtrace_rc_kernel recomputes the back-pointers around the path.
 #pragma once
@@ -29,13 +30,14 @@ namespace ka {
 
 constexpr int kTpCells = 4;                    // cells per lane
 constexpr int kTpTile = 64 * kTpCells;         // positions per tile
-constexpr int kTpBlock = 16;                   // frames per staging block
+constexpr int kTpBlock = 32;                   // frames per staging block (= the checkpoint interval)
 constexpr int kTpRing = 4;                     // LDS staging slots: the block being computed, the next one (landed), two more in flight
 constexpr int kTpRowBytes = 256;               // LDS pitch of a staged row in the row-by-row staging mode (64 columns)
-constexpr int kTpSlotBytes = 4096;             // LDS bytes of a staged block of 16 rows (any mode)
+constexpr int kTpSlotBytes = kTpBlock * 256;   // LDS bytes of a staged block of rows (any mode)
+constexpr int kTpStageBytes = 2048;            // publish staging: 512 B of lane 63's packets + the other lanes' scratch
 constexpr uint32_t kTpSentinel = 0x7fc0deadu;  // verification fill of the halo region (a NaN: no score is ever NaN)
 constexpr uint32_t kTpProgDone = 0x7fffffffu;  // progress word of a finished tile / of "no tile below"
-static_assert(kCkFrames == 2 * kTpBlock, "a checkpoint is taken at the end of every second block");
+static_assert(kCkFrames % kTpBlock == 0 && kTpBlock <= 32, "checkpoints fall on block ends; a block's packets are published by lanes 0..kTpBlock-1");
 
 struct TileTask {
     int32_t lat;        // index into the launch's Lattice array
@@ -202,7 +204,8 @@ struct TpTile {
     float absum;
     // LDS
     uint32_t lds_rows, lds_halo;   // byte addresses of this workgroup's staging rings
-    uint32_t lds_stage;            // per lane: byte address of its 16 bytes in frame 0's row of the publish staging area
+    uint32_t lds_stage;            // per lane: where frame 0 of a block drops the lane's four cells (lane 63: the packet row)
+    uint32_t lds_packets;          // the packet row: lane 63's cells of frame f at + 16 f
 };
 
 // One frame, F = its index in the block.  The LDS reads run TWO frames ahead of their use (an LDS read takes longer than
@@ -281,12 +284,12 @@ __device__ __forceinline__ void tp_frame(TpTile<M, ZL> &c, uint32_t t, float (&H
     // publish the state after frame t = slot t+1 of the upper boundary (lane 63's four cells)
     // (staged: every lane drops its four cells into this frame's 1-KB row of the LDS staging area - no EXEC change and
     //  no vector-memory instruction per frame; lane 63's go out at the end of the block, tp_publish_block)
-    if (live) *(__attribute__((address_space(3))) f32x4 *)(uintptr_t)(c.lds_stage + F * 1024) = c.S;
+    if (live) *(__attribute__((address_space(3))) f32x4 *)(uintptr_t)(c.lds_stage + F * 16) = c.S;
     cur = nxt;
     nxt = far;
 }
 
-// the 16 frames of a block.  LDS byte addresses of this block's slot (A[0]) and the next one's (A[1]): row 0 + the lane's
+// the frames of a block.  LDS byte addresses of this block's slot (A[0]) and the next one's (A[1]): row 0 + the lane's
 // two label columns, row 0 itself (column 0 = blank), packet 0 - per block, so that a frame adds only an immediate offset
 struct TpAddr {
     uint32_t l0, l1, r, h;
@@ -300,14 +303,14 @@ __device__ __forceinline__ void tp_block_frames(TpTile<M, ZL> &c, uint32_t tb, f
     if constexpr (F + 1 < kTpBlock) tp_block_frames<M, ZL, PITCH, GUARDED, F + 1>(c, tb, H, cur, nxt, A, NINF);
 }
 
-// end of a block: lane f < 16 fetches what lane 63 staged in frame f and stores it as slot tb + f + 1 (one write-through
-// store instruction for the block's 16 packets = 256 contiguous bytes); frames the tile did not compute store nothing
+// end of a block: lane f < kTpBlock fetches what lane 63 staged in frame f and stores it as slot tb + f + 1 (one write-through
+// store instruction for the block's packets = 512 contiguous bytes); frames the tile did not compute store nothing
 template <int M, bool ZL>
 __device__ __forceinline__ void tp_publish_block(TpTile<M, ZL> &c, uint32_t tb, int lane)
 {
     const int32_t t = (int32_t)tb + lane;
     if (lane < kTpBlock && t >= c.t_in && t < c.t_end) {
-        const f32x4 pk = lds_f32x4(c.lds_stage - (uint32_t)lane * 16u + (uint32_t)lane * 1024u + 63u * 16u);
+        const f32x4 pk = lds_f32x4(c.lds_packets + (uint32_t)lane * 16u);
         asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:16 sc1\n\ts_nop 1" : : "v"((uint32_t)lane * 16u), "v"(pk), "s"(c.out_block) : "memory");
     }
 }
@@ -326,12 +329,12 @@ __device__ __forceinline__ void tp_checkpoint(TpTile<M, ZL> &c, uint32_t t_next 
 // (lane = column; any row stride of the caller's array).  CONTIG = true (PITCH = 4 V; the array's rows are contiguous, V
 // columns): a block is copied as it lies in memory, 1 KB per LDS-DMA instruction - 4 (V = 64) or 3 (V = 39) instructions per block instead of 16; an LDS-DMA
 // instruction costs the wave ~60 cycles to issue whatever it moves, and with 16 of them the per-block staging took
-// longer than the block's 16 frames.
+// longer than the block's frames.
 template <int M, bool ZL, int PITCH, bool CONTIG>
 __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk, int32_t *meta, char *halo, gu32w_t prog, TileAux *aux,
                                             uint32_t lds_rows, uint32_t lds_halo, int verify, TpStats *stats_out)
 {
-    const uint32_t stat_lds = lds_halo + kTpRing * kTpBlock * 16 + 16 + kTpBlock * 1024;   // diagnostic words behind the staging areas
+    const uint32_t stat_lds = lds_halo + kTpRing * kTpBlock * 16 + 16 + kTpStageBytes;   // diagnostic words behind the staging areas
     if (threadIdx.x < 8) ((__attribute__((address_space(3))) uint32_t *)(uintptr_t)stat_lds)[threadIdx.x] = 0;
     // (KA_TP_VERIFY=4) shader cycles per phase of the block loop: [3] wait for the staged block, [4] its check + finiteness
     // sum, [5] progress store + poll, [6] requests (LDS-DMA issue), [7] publish + checkpoint
@@ -370,7 +373,11 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
     c.ck_off = (((uint32_t)c.base + 4u * (uint32_t)lane) & (uint32_t)d.ck_mask) * 4u;
     c.lds_rows = lds_rows;
     c.lds_halo = lds_halo;
-    c.lds_stage = lds_halo + kTpRing * kTpBlock * 16 + 16 + (uint32_t)lane * 16u;   // (16 bytes of progress looks sit in between)
+    // publish staging: frame F of a block drops every lane's four cells at lds_stage + 16 F - lane 63's (the packet) into
+    // the packet row, the other lanes' into scratch behind it (distinct addresses: no EXEC change, no bank conflict)
+    c.lds_packets = lds_halo + kTpRing * kTpBlock * 16 + 16;   // (16 bytes of progress looks sit in between)
+    c.lds_stage = lane == 63 ? c.lds_packets : c.lds_packets + kTpBlock * 16 + (uint32_t)lane * 16u;
+    static_assert(kTpBlock * 16 + 62 * 16 + (kTpBlock - 1) * 16 + 16 <= kTpStageBytes, "publish staging");
     // band of frame t_in (64-bit division once per tile; wave-uniform)
     {
         const uint64_t x = (uint64_t)c.L * (uint64_t)(uint32_t)c.t_in;
@@ -443,7 +450,7 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
                 __builtin_amdgcn_global_load_lds((gptr_t)(bp + off), (lptr_t)(dst + j * 1024), 16, 0, 0);
             }
         }
-        if (lane < kTpBlock) {       // slots tb .. tb+15 of the lower boundary (clamped to what exists): 16 lanes x 16 B, write-through data: sc1
+        if (lane < kTpBlock) {       // the block's slots of the lower boundary (clamped to what exists): one lane per slot, 16 B each, write-through data: sc1
             uint32_t s = tb + (uint32_t)lane;
             s = s < (uint32_t)c.t_in ? (uint32_t)c.t_in : (s > last_slot ? last_slot : s);
             __builtin_amdgcn_global_load_lds((gptr_t)(c.halo_in + (size_t)(s - (uint32_t)c.t_in) * 16), (lptr_t)(lchar_t)(uintptr_t)(c.lds_halo + slot * (kTpBlock * 16)), 16, 0, 16);
@@ -474,7 +481,7 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
     auto landed_block = [&](int32_t k) {
         const uint32_t slot = ring(k);
         // (all reads first, then the sum: written as one accumulation chain hipcc waited for every read in turn -
-        //  1700 cycles per block, more than the block's 16 frames)
+        //  1700 cycles per 16 frames, more than the frames themselves)
         const uint32_t r = c.lds_rows + slot * kTpSlotBytes + (uint32_t)lane * 4u;
         constexpr int kReads = !CONTIG ? kTpBlock : (kTpBlock * PITCH + 255) / 256;
         float v[kReads];
@@ -560,7 +567,7 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
             phase(-1);
             tp_publish_block(c, tb, lane);
             tail1 = 1;
-            if ((tb & kTpBlock) && tb + kTpBlock < c.T) {
+            if ((tb + kTpBlock) % kCkFrames == 0 && tb + kTpBlock < c.T) {
                 tp_checkpoint(c, tb + kTpBlock);
                 ++tail1;
             }
@@ -568,7 +575,7 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
         } else {
             tp_block_frames<M, ZL, PITCH, true, 0>(c, tb, H, cur, nxt, A, NINF);
             tp_publish_block(c, tb, lane);
-            if ((tb & kTpBlock) && (int32_t)(tb + kTpBlock) <= c.t_end && tb + kTpBlock < c.T) tp_checkpoint(c, tb + kTpBlock);
+            if ((tb + kTpBlock) % kCkFrames == 0 && (int32_t)(tb + kTpBlock) <= c.t_end && tb + kTpBlock < c.T) tp_checkpoint(c, tb + kTpBlock);
             // (a partial block issued an unknown number of stores: its count stays 0, a lower bound, and the waits that
             //  cover it wait for a store or two more than they must)
         }
@@ -654,7 +661,8 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
 // finish.  The tile a workgroup runs is drawn from a ticket counter, not from its index: tasks are sorted by first frame,
 // so whatever order the dispatcher starts workgroups in, a tile's producer holds an earlier ticket and is running or done
 // - the earliest unfinished ticket can always run to completion.
-constexpr unsigned kTpLdsRequest = 40 * 1024;   // used: 16 KB rows + 1 KB packets + 16 KB publish staging
+constexpr unsigned kTpLdsRequest = 40 * 1024;   // used: 32 KB rows + 2 KB packets + 2 KB publish staging
+static_assert(kTpRing * kTpSlotBytes + kTpRing * kTpBlock * 16 + 16 + kTpStageBytes + 64 <= kTpLdsRequest, "LDS budget");
 template <int M, int PITCH, bool CONTIG>
 __global__ __launch_bounds__(64) void forward_tp_kernel(const Lattice *__restrict__ lats, const TileTask *__restrict__ tasks, int n_tasks,
                                                         int32_t *meta, char *halo, uint32_t *prog, TileAux *aux, uint32_t *ticket, int verify, TpStats *stats)

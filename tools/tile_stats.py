@@ -19,7 +19,7 @@ print("forward_ms", b.engine.last_kernel_ms()["forward"])
 out = np.zeros((4096, 8), np.uint64)
 n = b.engine.lib.ka_debug_tile_stats(b.engine.handle, out.ctypes.data, 4096)
 t0 = 0
-print("cycles per frame inside the 16-frame blocks (tiles 0..):", np.round((out[:n, 4] >> np.uint64(32)).astype(float) / np.maximum(1, (out[:n, 3] - out[:n, 2]).astype(float)), 1)[:12])
+print("cycles per frame inside the frame blocks (tiles 0..):", np.round((out[:n, 4] >> np.uint64(32)).astype(float) / np.maximum(1, (out[:n, 3] - out[:n, 2]).astype(float)), 1)[:12])
 out[:n, 4] &= np.uint64(0xffffffff)
 print("shader clock while the tiles ran (GHz):", np.round(out[:n, 7].astype(float) / (out[:n, 5].astype(float) * 10), 2)[:12])
 print(" tile   t_in  t_end frames  start_us alive_us wait_us waits ns/frame(busy)  xcc se cu simd slot")
