@@ -1501,19 +1501,22 @@ __device__ __forceinline__ uint64_t lane_field(uint32_t count, uint32_t first)
     asm("s_bfm_b64 %0, %1, %2" : "=s"(m) : "s"(count), "s"(first));
     return m;
 }
-// One frame of the window recurrence for max_move = 4, written out so that it costs 23 vector instructions (25 where the
+// One frame of the window recurrence for max_move = 4, written out so that it costs 21 vector instructions (23 where the
 // window touches a band edge) instead of the 29 hipcc makes of the cell_blank / cell_label formulation:
-//   * the three operands that come from the lane below (label pb-1 for both cells, blank pb-2) enter their adds through
-//     DPP (v_add_f32_dpp .. wave_ror:1) instead of through a v_mov_dpp each, and the blank cell's move-3 candidate
-//     score(pb-3) + e0 is the move-1 candidate score(pb-1) + e0 of the lane below - e0 is the same in every lane - so it
-//     is one more rotation of a sum that exists already: the same float add on the same operands, in another lane;
-//   * DPP takes no scalar operand, so the blank emission lp[t, 0] is fetched into a VGPR with a second ds_bpermute
-//     (address 0) next to the label emission's; both are issued one frame ahead and waited for at the end of the block;
+//   * the label cell's two operands from the lane below (label pb-1, blank pb-2) enter their adds through DPP
+//     (v_add_f32_dpp .. wave_ror:1) instead of through a v_mov_dpp each;
+//   * the blank cell's candidates from the lane below are rotations of ONE sum: score(pb-1) + e0 = ror(sl + e0) and
+//     score(pb-3) + e0 = ror of that again - e0 is the same in every lane, so this is the same float add on the same
+//     operands, carried out in another lane.  (DPP takes no scalar operand.  KA_RC_E0_SCALAR = 0 fetches e0 into a VGPR
+//     with a second ds_bpermute instead, so that all three lane-below operands go through DPP adds: two vector
+//     instructions fewer, and slower - the LDS pipe is shared by the CU's four SIMDs);
+//   * the label emission is gathered one frame ahead and waited for at the end of the block;
 //   * `open` (the cells the walk can reach lie inside the band at every frame of the chunk, the usual case): the band
 //     select is branched over on the scalar unit - the maxima stay in sb / sl as they are.
 // Software hazards the assembler does not see to (DPP reads a VGPR written by the previous VALU instruction: 2 wait
-// states): sb / sl are last written by the selects, with the s_waitcnt and the next block's two ds_bpermute between them
-// and the next DPP read; t1 is written 6 instructions before its DPP read.
+// states): sb / sl are last written by the selects, with the s_waitcnt and the next block's gather, v_readfirstlane
+// and first add between them and the next DPP read; inside the block every DPP source is written at least three
+// instructions earlier (an s_nop fills in where the veto is compiled out).
 // `word` takes 4 code bits per frame exactly as cell_blank<4> / cell_label<4> would shift them in.
 #ifndef KA_RC_DIAG
 #define KA_RC_DIAG 0
