@@ -189,7 +189,6 @@ struct TpTile {
     uint32_t lane_off;
     const char *halo_in;    // slot j of the lower boundary at halo_in + (j - t_in) * 16
     char *halo_out;         // slot j of the upper boundary at halo_out + (j - t_in) * 16 (the top tile writes to a boundary nobody reads)
-    const char *out_block;  // slot 16 kb of the block being computed (frame 16 kb + f publishes slot f + 1 of it)
     gu32w_t prog_in, prog_out;
     char *ck;               // checkpoint k (scores after frame 32 (k + 1) - 1) at ck + k * ck_pitch
     uint32_t ck_pitch;
@@ -311,7 +310,10 @@ __device__ __forceinline__ void tp_publish_block(TpTile<M, ZL> &c, uint32_t tb, 
     const int32_t t = (int32_t)tb + lane;
     if (lane < kTpBlock && t >= c.t_in && t < c.t_end) {
         const f32x4 pk = lds_f32x4(c.lds_packets + (uint32_t)lane * 16u);
-        asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:16 sc1\n\ts_nop 1" : : "v"((uint32_t)lane * 16u), "v"(pk), "s"(c.out_block) : "memory");
+        // slot tb of the upper boundary (frame tb + f publishes slot tb + f + 1); worked out here, after the frames: two
+        // scalar registers that are not live across them
+        const char *out_block = c.halo_out + ((int64_t)tb - (int64_t)c.t_in) * 16;
+        asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:16 sc1\n\ts_nop 1" : : "v"((uint32_t)lane * 16u), "v"(pk), "s"(out_block) : "memory");
     }
 }
 
@@ -545,7 +547,6 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
                      : "=&v"(rc), "=&v"(rn), "=&v"(hc), "=&v"(hn) : "s"(rc), "s"(rn), "s"(hc), "s"(hn));
         TpAddr A[2] = {{rc + (uint32_t)c.la0, rc + (uint32_t)c.la1, rc, hc}, {rn + (uint32_t)c.la0, rn + (uint32_t)c.la1, rn, hn}};
         asm volatile("" : "+v"(A[0].l0), "+v"(A[0].l1), "+v"(A[1].l0), "+v"(A[1].l1));   // (keep the four sums: no re-add per frame)
-        c.out_block = c.halo_out + ((int64_t)tb - (int64_t)c.t_in) * 16;
         if (it == kb0) {
             // prime the two-frame read pipeline at the block's frames 0 and 1; when the tile starts later in the block,
             // the skipped frames in front of it shift the pipeline along (and take H afresh) exactly like computed ones
