@@ -146,6 +146,12 @@ int ka_debug_tile_stats(ka_engine *e, uint64_t *out, int32_t max_tasks);
  * last frame of every chunk followed by that of every super-chunk (returns how many values), and optionally its
  * chunk maps (one row of ring-size bytes per chunk). */
 int ka_debug_chunk_entries(ka_engine *e, int32_t *out, int32_t max_entries, uint8_t *map0_out, int64_t map0_max);
+/* Host-side probe of the tiled form's plan (no GPU needed): for a lattice of T frames, S phonemes, V classes the
+ * 256-position tiles the band of align.py:64-65 ever touches and the frames [t_in, t_end) each of them is alive in.
+ * Returns the number of tiles (t_in / t_end are filled up to max_tiles), 0 if the shape is not run in the tiled form,
+ * a negative status for bad arguments.  checkpoint_pitch (may be NULL): bytes per checkpoint row. */
+int ka_debug_plan_tiles(int64_t T, int64_t S, int32_t V, int32_t beam_size, int32_t max_move, int32_t *t_in, int32_t *t_end,
+                        int32_t max_tiles, int64_t *checkpoint_pitch);
 int ka_engine_set_profiling(ka_engine *e, int32_t on);
 int ka_engine_last_kernel_ms(ka_engine *e, float ms[4]);
 

@@ -32,7 +32,7 @@ EXPORTS = [
     "ka_engine_last_kernel_ms", "ka_log_softmax_f32", "ka_hash_logprobs_f32", "ka_hash_labels_i32",
     "ka_hash_logprobs_batch_f32", "ka_hash_labels_batch_i32", "ka_engine_set_mode", "ka_lstm_step_f32",
     "ka_lstm_layer_f32", "ka_window_energy_f32", "ka_stft_frames_f32", "ka_power_f32", "ka_power_to_db_f32",
-    "ka_debug_tile_stats", "ka_engine_set_backtrace", "ka_debug_chunk_entries",
+    "ka_debug_tile_stats", "ka_engine_set_backtrace", "ka_debug_chunk_entries", "ka_debug_plan_tiles",
 ]
 
 
@@ -99,6 +99,8 @@ def load_library():
     L.ka_engine_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     L.ka_debug_chunk_entries.restype = ctypes.c_int
     L.ka_debug_chunk_entries.argtypes = [vp, vp, i32, vp, i64]
+    L.ka_debug_plan_tiles.restype = ctypes.c_int
+    L.ka_debug_plan_tiles.argtypes = [i64, i64, i32, i32, i32, vp, vp, i32, vp]
     L.ka_debug_tile_stats.restype = ctypes.c_int
     L.ka_debug_tile_stats.argtypes = [vp, vp, i32]
     L.ka_log_softmax_f32.restype = ctypes.c_int

@@ -877,6 +877,22 @@ int ka_debug_chunk_entries(ka_engine *e, int32_t *out, int32_t max_entries, uint
     return (int)n;
 }
 
+int ka_debug_plan_tiles(int64_t T, int64_t S, int32_t V, int32_t beam_size, int32_t max_move, int32_t *t_in, int32_t *t_end,
+                        int32_t max_tiles, int64_t *checkpoint_pitch)
+{
+    Shape sh;
+    if (max_tiles < 0 || (max_tiles > 0 && (!t_in || !t_end)) || !shape_of(T, S, V, beam_size, max_move, sh))
+        return fail(KA_ERR_BAD_ARGS, "ka_debug_plan_tiles: bad arguments");
+    plan_tiles(sh, V, beam_size, max_move);
+    if (!sh.tileable) return 0;
+    for (size_t b = 0; b < sh.t_in.size() && b < (size_t)max_tiles; ++b) {
+        t_in[b] = sh.t_in[b];
+        t_end[b] = sh.t_end[b];
+    }
+    if (checkpoint_pitch) *checkpoint_pitch = (int64_t)sh.ck_pitch;
+    return (int)sh.t_in.size();
+}
+
 int ka_debug_tile_stats(ka_engine *e, uint64_t *out, int32_t max_tasks)
 {
     if (!e || !out || max_tasks < 0) return fail(KA_ERR_BAD_ARGS, "ka_debug_tile_stats: bad arguments");
