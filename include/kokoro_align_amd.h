@@ -32,8 +32,9 @@ extern "C" {
 #define KA_ERR_HIP (-3)       /* HIP runtime error, text in ka_last_error() */
 #define KA_ERR_NOMEM (-4)
 #define KA_ERR_BAD_LABEL (-5) /* label outside [0,V): reference raises IndexError at align.py:77 */
-#define KA_ERR_NONFINITE (-7) /* tiled form only: an infinity among the log-probs of a lattice whose band is wider than 1009
-                                 positions (narrower ones are handed to the exact kernels; -inf is legal there) */
+#define KA_ERR_NONFINITE (-7) /* explicit KA_MODE_TILED only: an infinity among the log-probs of a lattice whose band is wider
+                                 than 1009 positions.  KA_MODE_AUTO answers such lattices (the exact kernels for bands up to
+                                 1009, the generic kernels above): -inf is legal input, as in the reference */
 #define KA_ERR_INTERNAL (-8)  /* tiled form: a tile's hand-off timed out (an internal error, never an input condition) */
 #define KA_ERR_NAN (-6)       /* a log-prob is NaN: the reference's np.argmax treats NaN as the maximum (align.py:83); that
                                  is not reproduced - the lattice is rejected (fast path, V <= 64, band <= 1009 or tiled form) */
@@ -112,7 +113,14 @@ int ka_batch_finish(ka_engine *e, float *total_score, int32_t *status);
  *   KA_MODE_WAVE_EXACT  one wavefront per lattice, every back-pointer stored (2 bits per band cell).
  *   KA_MODE_WORKGROUP   four wavefronts per lattice with an LDS hand-off per frame; back-pointers stored.  The
  *                       shortest forward pass for one lattice, but WAVE's two kernels together are faster.
- *   KA_MODE_AUTO        (default) WAVE.
+ *   KA_MODE_TILED       one wavefront per 256-position TILE of the label axis, the tiles of a lattice run as a pipeline
+ *                       (scores only, checkpoints as WAVE): a lone lattice or a book's few dozen chapters, and ANY band
+ *                       width (beam_size >= 2L is the reference's unbanded DP).  Non-finite log-probs: bands up to 1009 are
+ *                       redone by the exact kernels, wider ones return KA_ERR_NONFINITE in this explicit mode.
+ *   KA_MODE_AUTO        (default) per launch: lattices whose band is wider than 1009 positions always run TILED (and are
+ *                       handed to the generic kernels by ka_batch_finish if their log-probs turn out to hold infinities);
+ *                       the others run TILED while the launch is too small to fill the chip with one wavefront per lattice
+ *                       (the rule is in ka_engine.hip, next to its measurements), else WAVE.
  * Results are identical in every form. */
 #define KA_MODE_AUTO 0
 #define KA_MODE_WAVE 1
@@ -138,7 +146,14 @@ int ka_engine_set_backtrace(ka_engine *e, int32_t how);
 /* Per-kernel timing of the LAST enqueued batch, measured with HIP events recorded on the
  * launch stream: ms[0] label prep, ms[1] forward DP, ms[2] backtrace walk, ms[3] output
  * gathers (best_labels / best_scores).  Enable before the call; costs one event per kernel. */
-/* Diagnostics of the tiled form (with KA_TP_VERIFY=4 in the environment): per tile of the last batch, 8 values
+/* Self-checks of the tiled form's hand-off, a combination of:
+ *   1  the halo region is filled with a NaN sentinel before the launch and every packet a tile consumes is checked
+ *      against it: a packet read before it was written gives the lattice KA_ERR_INTERNAL (tests)
+ *   2  every publish waits for all of the tile's outstanding memory operations (rules out the counted waits)
+ *   4  per-tile phase stamps for ka_debug_tile_stats
+ * 0 (default) = none.  Applies to the engine's later launches. */
+int ka_engine_set_verify(ka_engine *e, int32_t flags);
+/* Diagnostics of the tiled form (after ka_engine_set_verify(e, 4)): per tile of the last batch, 8 values
  * {descriptor, tile, t_in, t_end, ticks spent waiting for the tile below, ticks alive, waits, start tick}, 100 MHz
  * ticks, in ticket order.  Returns the number of tiles written (at most max_tasks). */
 int ka_debug_tile_stats(ka_engine *e, uint64_t *out, int32_t max_tasks);

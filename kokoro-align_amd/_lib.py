@@ -33,6 +33,7 @@ EXPORTS = [
     "ka_hash_logprobs_batch_f32", "ka_hash_labels_batch_i32", "ka_engine_set_mode", "ka_lstm_step_f32",
     "ka_lstm_layer_f32", "ka_window_energy_f32", "ka_stft_frames_f32", "ka_power_f32", "ka_power_to_db_f32",
     "ka_debug_tile_stats", "ka_engine_set_backtrace", "ka_debug_chunk_entries", "ka_debug_plan_tiles",
+    "ka_engine_set_verify",
 ]
 
 
@@ -93,6 +94,8 @@ def load_library():
     L.ka_engine_set_mode.argtypes = [vp, i32]
     L.ka_engine_set_backtrace.restype = ctypes.c_int
     L.ka_engine_set_backtrace.argtypes = [vp, i32]
+    L.ka_engine_set_verify.restype = ctypes.c_int
+    L.ka_engine_set_verify.argtypes = [vp, i32]
     L.ka_engine_set_profiling.restype = ctypes.c_int
     L.ka_engine_set_profiling.argtypes = [vp, i32]
     L.ka_engine_last_kernel_ms.restype = ctypes.c_int
@@ -187,6 +190,11 @@ class Engine:
         """'auto' | 'serial' (chunk after chunk) | 'parallel' (every chunk at once; ka_parallel_bt.hpp)"""
         code = {"auto": 0, "serial": 1, "parallel": 2}[how] if isinstance(how, str) else int(how)
         check(self.lib.ka_engine_set_backtrace(self.handle, code), "ka_engine_set_backtrace")
+
+    def set_verify(self, flags):
+        """Self-checks of the tiled form's hand-off (ka_engine_set_verify): 1 = sentinel-filled halos, every consumed packet
+        checked; 2 = full drain before every publish; 4 = per-tile phase stamps for ka_debug_tile_stats; 0 = off."""
+        check(self.lib.ka_engine_set_verify(self.handle, int(flags)), "ka_engine_set_verify")
 
     def set_profiling(self, on=True):
         check(self.lib.ka_engine_set_profiling(self.handle, int(bool(on))), "ka_engine_set_profiling")

@@ -181,6 +181,12 @@ struct ka_engine {
     int32_t backtrace = KA_BACKTRACE_AUTO;
     int32_t n_simd = 1024;                 // SIMDs of the device = persistent workers of the tiled form
     std::vector<int32_t> wide_tiled;       // last batch: lattices in the tiled form that the exact kernels cannot redo
+    // ... and what ka_batch_finish needs to hand those of them that the tiled form declined (non-finite log-probs) to the
+    // generic kernels: the caller's buffers (valid until finish returns, by the contract of the split form)
+    struct Redo { const float *lp; const int32_t *labels; int32_t *path, *lab_out; float *sc_out; int64_t T, S, ld; int32_t idx; };
+    std::vector<Redo> redo;
+    int32_t last_V = 0, last_beam = 0, last_max_move = 0, last_mem = KA_MEM_DEVICE;
+    int32_t verify = 0;                    // ka_engine_set_verify: self-checks of the tiled form's hand-off
     size_t dbg_entry = 0, dbg_entry_n = 0, dbg_map0 = 0, dbg_map0_bytes = 0;   // last batch, descriptor 0: chunk entries and chunk maps
     size_t dbg_tasks = 0, dbg_stats = 0, dbg_n_tasks = 0;   // last batch: workspace offsets of the tile tasks and their timing records
 };
@@ -369,6 +375,14 @@ int ka_engine_set_backtrace(ka_engine *e, int32_t how)
     return KA_OK;
 }
 
+int ka_engine_set_verify(ka_engine *e, int32_t flags)
+{
+    if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
+    if (flags < 0 || flags > 7) return fail(KA_ERR_BAD_ARGS, "ka_engine_set_verify: flags are a combination of 1, 2 and 4");
+    e->verify = flags;
+    return KA_OK;
+}
+
 int ka_engine_set_profiling(ka_engine *e, int32_t on)
 {
     if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
@@ -397,7 +411,7 @@ constexpr int64_t kAutoParallelBacktraceFrameRatio = 256;
 static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, const int64_t *T, int32_t V,
                         const int64_t *ld, const int32_t *const *labels, const int64_t *S, int32_t beam_size,
                         int32_t max_move, int32_t *const *best_path, int32_t *const *best_labels,
-                        float *const *best_scores, int32_t mem, hipStream_t stream)
+                        float *const *best_scores, int32_t mem, hipStream_t stream, bool force_generic = false)
 {
     if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
     if (e->pending) return fail(KA_ERR_BAD_ARGS, "a batch is already enqueued: call ka_batch_finish first");
@@ -410,6 +424,11 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
     e->stream_last = stream;
     e->have_times = false;
     e->wide_tiled.clear();
+    e->redo.clear();
+    e->last_V = V;
+    e->last_beam = beam_size;
+    e->last_max_move = max_move;
+    e->last_mem = mem;
     if (n == 0) {
         e->pending = true;
         return KA_OK;
@@ -431,7 +450,7 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
     {
         const bool all = e->mode == KA_MODE_TILED;
         const bool few = e->mode == KA_MODE_AUTO && n_fast_shaped <= kAutoTiledMaxLattices;
-        for (int32_t i = 0; i < n; ++i) {
+        for (int32_t i = 0; i < n && !force_generic; ++i) {
             if (!(all || (e->mode == KA_MODE_AUTO && (few || !sh[i].fast)))) continue;
             plan_tiles(sh[i], V, beam_size, max_move);
             sh[i].tiled = sh[i].tileable;
@@ -443,15 +462,11 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
     // fill the chip with one backtrace wavefront each (it recomputes the whole band of every chunk, ~8x the serial
     // form's work, but all chunks at once)
     {
-        int32_t n_ck = 0;   // lattices that end in backtrace_rc
-        for (int32_t i = 0; i < n; ++i)
-            n_ck += (sh[i].tiled || (sh[i].fast && e->mode != KA_MODE_WORKGROUP && e->mode != KA_MODE_WAVE_EXACT && sh[i].T < (int64_t(1) << 26))) ? 1 : 0;
         int64_t sum_T = 0, max_T = 1;
         for (int32_t i = 0; i < n; ++i) {
             sum_T += sh[i].T;
             max_T = std::max<int64_t>(max_T, sh[i].T);
         }
-        (void)n_ck;
         const bool par = e->backtrace == KA_BACKTRACE_PARALLEL || (e->backtrace == KA_BACKTRACE_AUTO && sum_T < kAutoParallelBacktraceFrameRatio * max_T);
         for (int32_t i = 0; i < n; ++i)
             sh[i].par_bt = par && (sh[i].tiled || (sh[i].fast && e->mode != KA_MODE_WORKGROUP && e->mode != KA_MODE_WAVE_EXACT));
@@ -584,7 +599,10 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
             e->dbg_map0 = cv[i].map0;
             e->dbg_map0_bytes = sh[i].par_bt ? (size_t)chunks_of_T(sh[i].T) * ((sh[i].tiled ? sh[i].ck_pitch : 4096) / 4) : 0;
         }
-        if (sh[i].tiled && !sh[i].fast) e->wide_tiled.push_back(i);
+        if (sh[i].tiled && !sh[i].fast) {
+            e->wide_tiled.push_back(i);
+            e->redo.push_back({log_probs[i], labels[i], best_path[i], best_labels[i], best_scores[i], T[i], S[i], ld[i], i});
+        }
     }
     // ---- tile tasks, sorted by first frame (then tile, then lattice): a tile's producer holds an earlier ticket ----
     if (n_tiled) {
@@ -664,8 +682,8 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
     Form form = kFormWaveExact;
     if (n_tiled > 0) {
         const unsigned grid = (unsigned)n_tasks, lds = ka::kTpLdsRequest;
-        // KA_TP_VERIFY=1 (tests): every halo slot starts as a NaN pattern and a tile that consumes one reports KA_ERR_INTERNAL
-        static const int verify = [] { const char *v = std::getenv("KA_TP_VERIFY"); return v ? std::atoi(v) : 0; }();
+        // ka_engine_set_verify(1) (tests): every halo slot starts as a NaN pattern and a tile that consumes one reports KA_ERR_INTERNAL
+        const int verify = e->verify;
         if (verify & 1) {
             size_t lo_b = ~size_t(0), hi_b = 0;
             for (int32_t i = 0; i < n; ++i)
@@ -817,15 +835,47 @@ int ka_batch_finish(ka_engine *e, float *total_score, int32_t *status)
     KA_HIP(guard.enter(e->device));
     KA_HIP(hipStreamSynchronize(e->stream_last));
     if (e->profiling && e->n_last > 0) e->have_times = true;
-    // a lattice in the tiled form whose band is wider than the exact kernels' ring and whose log-probs are not all
-    // finite (flag set by the forward kernel) has no result
-    for (int32_t i : e->wide_tiled) {
-        int32_t *m = e->h_meta + 4 * (size_t)i;
-        if (m[0] == KA_OK && (m[2] & ka::kFlagDeclined)) m[0] = KA_ERR_NONFINITE;
+    // A lattice in the tiled form whose band is wider than the exact kernels' ring and whose log-probs are not all
+    // finite (flag set by the forward kernel) has no result yet: the scores-only forms are valid only while "live" and
+    // "score > -inf" coincide.  The reference answers such input (align.py:67-85 tracks the live set explicitly), so in
+    // KA_MODE_AUTO those lattices are handed to the generic kernels now, into the caller's buffers; an explicit
+    // KA_MODE_TILED reports KA_ERR_NONFINITE.
+    const int32_t n_all = e->n_last;
+    std::vector<int32_t> meta(e->h_meta, e->h_meta + 4 * (size_t)n_all);
+    std::vector<ka_engine::Redo> again;
+    for (const ka_engine::Redo &r : e->redo) {
+        int32_t *m = meta.data() + 4 * (size_t)r.idx;
+        if (m[0] != KA_OK || !(m[2] & ka::kFlagDeclined)) continue;
+        if (e->mode == KA_MODE_TILED) m[0] = KA_ERR_NONFINITE;
+        else again.push_back(r);
+    }
+    if (!again.empty()) {
+        const int32_t m = (int32_t)again.size();
+        std::vector<const float *> lp(m);
+        std::vector<const int32_t *> lab(m);
+        std::vector<int32_t *> path(m), lab_out(m);
+        std::vector<float *> sc(m);
+        std::vector<int64_t> T(m), S(m), ld(m);
+        for (int32_t j = 0; j < m; ++j) {
+            lp[j] = again[j].lp; lab[j] = again[j].labels; path[j] = again[j].path; lab_out[j] = again[j].lab_out; sc[j] = again[j].sc_out;
+            T[j] = again[j].T; S[j] = again[j].S; ld[j] = again[j].ld;
+        }
+        const bool prof = e->profiling;
+        e->profiling = false;      // the events keep the times of the batch itself
+        const hipStream_t stream = e->stream_last;
+        int rc = enqueue_impl(e, m, lp.data(), T.data(), e->last_V, ld.data(), lab.data(), S.data(), e->last_beam, e->last_max_move,
+                              path.data(), lab_out.data(), sc.data(), e->last_mem, stream, /*force_generic=*/true);
+        e->profiling = prof;
+        e->pending = false;
+        if (rc != KA_OK) return rc;
+        KA_HIP(hipStreamSynchronize(stream));
+        for (int32_t j = 0; j < m; ++j) std::memcpy(meta.data() + 4 * (size_t)again[j].idx, e->h_meta + 4 * (size_t)j, 16);
+        e->n_last = n_all;
+        e->redo.clear();
     }
     int first_bad = KA_OK;
-    for (int32_t i = 0; i < e->n_last; ++i) {
-        const int32_t *m = e->h_meta + 4 * (size_t)i;
+    for (int32_t i = 0; i < n_all; ++i) {
+        const int32_t *m = meta.data() + 4 * (size_t)i;
         if (status) status[i] = m[0];
         if (total_score) std::memcpy(&total_score[i], &m[3], 4);
         if (m[0] != KA_OK && first_bad == KA_OK) {
@@ -834,7 +884,7 @@ int ka_batch_finish(ka_engine *e, float *total_score, int32_t *status)
                                                       : m[0] == KA_ERR_BAD_LABEL ? ": label outside [0, V)"
                                                       : m[0] == KA_ERR_INTERNAL  ? ": internal error in the tile hand-off"
                                                       : m[0] == KA_ERR_NAN       ? ": a log-prob is NaN"
-                                                      : m[0] == KA_ERR_NONFINITE ? ": log-probs with infinities in a band wider than 1009 positions (use KA_MODE_WAVE)"
+                                                      : m[0] == KA_ERR_NONFINITE ? ": log-probs with infinities in a band wider than 1009 positions (KA_MODE_TILED cannot answer it: use KA_MODE_AUTO)"
                                                                                  : ": failed");
         }
     }
@@ -909,7 +959,7 @@ int ka_debug_tile_stats(ka_engine *e, uint64_t *out, int32_t max_tasks)
         uint64_t *o = out + 8 * i;
         o[0] = (uint64_t)tk[i].lat; o[1] = (uint64_t)tk[i].tile; o[2] = (uint64_t)tk[i].t_in; o[3] = (uint64_t)tk[i].t_end;
         o[4] = st[i].wait_ticks; o[5] = st[i].total_ticks; o[6] = st[i].spins; o[7] = st[i].start_tick;
-        if (i == 0 || i == 10 || i == 20) std::fprintf(stderr, "[ka_debug_tile_stats] ticket %zu cycles per phase: wait %llu, check+sum %llu, progress %llu, requests %llu, publish %llu\n", i,
+        if ((e->verify & 4) && (i == 0 || i == 10 || i == 20)) std::fprintf(stderr, "[ka_debug_tile_stats] ticket %zu cycles per phase: wait %llu, check+sum %llu, progress %llu, requests %llu, publish %llu\n", i,
                                  (unsigned long long)(uint32_t)st[i].phase[0], (unsigned long long)(st[i].phase[0] >> 32), (unsigned long long)(uint32_t)st[i].phase[1],
                                  (unsigned long long)(st[i].phase[1] >> 32), (unsigned long long)st[i].phase[2]);
     }

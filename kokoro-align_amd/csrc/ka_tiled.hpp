@@ -144,20 +144,23 @@ __device__ __forceinline__ void tp_prog_load(uint32_t &dst, gu32w_t word /* unif
     asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 sc1" : "+v"(dst) : "v"(0u), "s"(word) : "memory");
 }
 // progress of the tile below must reach `need` leading slots; polled relaxed with a sleep that grows while far away.
-// Bounded: a tile whose producer has not delivered within ~4 s of wall clock gives up (returns false; the lattice gets
-// KA_ERR_INTERNAL) instead of hanging the GPU - this can only be a bug in the hand-off, never an input.
+// Bounded by a STALL detector: a tile whose producer has not advanced its progress word for ~4 s of wall clock gives up
+// (returns false; the lattice gets KA_ERR_INTERNAL) instead of hanging the GPU - this can only be a bug in the hand-off,
+// never an input.  The clock restarts whenever the polled word moves: a tile whose producer is healthy but far behind
+// (a long lattice with every tile resident, a queue that is time-sliced with another process) waits as long as it takes.
 // Hysteresis: a tile that does have to wait waits for `want` >= need (two blocks more): the poll it carries into a block
 // start is a block old, so a tile sitting exactly at the limit would pay a poll round trip (~1 us) at every block;
 // after one longer wait it stays ahead of its stale information for as long as it is not faster than its producer.
 struct TpStats {
     unsigned long long phase[3];   // shader cycles: (wait | check+sum << 32), (progress | requests << 32), (publish+checkpoint)
-    unsigned long long wait_ticks, total_ticks, spins, start_tick;   // 100 MHz ticks (KA_TP_VERIFY & 4: ka_debug_tile_stats)
+    unsigned long long wait_ticks, total_ticks, spins, start_tick;   // 100 MHz ticks (ka_engine_set_verify(4): ka_debug_tile_stats)
 };
 // (diagnostic counters - number of waits, 100 MHz ticks spent in them - live in two LDS words at `stat_lds`)
 __device__ __forceinline__ bool tp_wait_progress(gu32w_t word, uint32_t need, uint32_t want, uint32_t have, uint32_t stat_lds)
 {
     if (have >= need) return true;
     const uint64_t t0 = wall_clock64();   // 100 MHz
+    uint64_t t_moved = t0;
     __attribute__((address_space(3))) uint32_t *st = (__attribute__((address_space(3))) uint32_t *)(uintptr_t)stat_lds;
     st[0] += 1;
     for (;;) {
@@ -168,13 +171,15 @@ __device__ __forceinline__ bool tp_wait_progress(gu32w_t word, uint32_t need, ui
         uint32_t v = 0;
         tp_prog_load(v, word);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) : : "memory");
-        have = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-        const uint64_t waited = wall_clock64() - t0;
+        const uint32_t now_have = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+        const uint64_t now = wall_clock64();
+        if (now_have != have) t_moved = now;
+        have = now_have;
         if (have >= want) {
-            st[1] += (uint32_t)waited;
+            st[1] += (uint32_t)(now - t0);
             return true;
         }
-        if (waited > 400000000ull) return false;
+        if (now - t_moved > 400000000ull) return false;
     }
 }
 
@@ -338,7 +343,7 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
 {
     const uint32_t stat_lds = lds_halo + kTpRing * kTpBlock * 16 + 16 + kTpStageBytes;   // diagnostic words behind the staging areas
     if (threadIdx.x < 8) ((__attribute__((address_space(3))) uint32_t *)(uintptr_t)stat_lds)[threadIdx.x] = 0;
-    // (KA_TP_VERIFY=4) shader cycles per phase of the block loop: [3] wait for the staged block, [4] its check + finiteness
+    // (ka_engine_set_verify(4)) shader cycles per phase of the block loop: [3] wait for the staged block, [4] its check + finiteness
     // sum, [5] progress store + poll, [6] requests (LDS-DMA issue), [7] publish + checkpoint
     unsigned long long ph = 0;
     auto phase = [&](int w) {
@@ -478,7 +483,7 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
                      : : "s"(younger), "i"(kIssued) : "memory", "scc");
     };
     bool stale = false;
-    // block k has landed in LDS: the finiteness sum over its rows, and (KA_TP_VERIFY=1: the host filled the halo region
+    // block k has landed in LDS: the finiteness sum over its rows, and (ka_engine_set_verify(1): the host filled the halo region
     // with a NaN pattern no score can have) no packet this tile is going to consume may still hold that pattern
     auto landed_block = [&](int32_t k) {
         const uint32_t slot = ring(k);

@@ -15,7 +15,7 @@ import os
 
 import numpy as np
 
-from .align import _host_log_softmax, align as _write_align, ctc_best_path_device, log_softmax_device
+from .align import _host_log_softmax, align as _write_align, log_softmax_device
 from .encoder import decode_text, encode_text, is_valid_text, merge_repeated
 
 
@@ -166,15 +166,32 @@ def best_path_files(logits_files, voca_files, best_path_files_out, device=None, 
             t = logits if hasattr(logits, "detach") else torch.from_numpy(np.ascontiguousarray(logits, np.float32))
             lps.append(log_softmax_device(t.to(dev)))
         labs.append(read_transcript(vf))
-    results = ctc_best_path_device(lps, labs)      # raises ValueError like the reference
-    for (_, _, bf), (p, l, s) in zip(todo, results):
+    # One launch for all chapters, but the reference's per-file progress (run_example.py:248-254 loops the files: what was
+    # written before a failing chapter stays written and is skipped on the rerun): every chapter whose status is 0 gets
+    # its file, then the first failing chapter raises what the reference's best_path() would have raised for it.
+    from . import _lib
+    from .align import DeviceBatch
+    for lp in lps:
+        if lp.shape[0] == 0:
+            raise IndexError("list index out of range")
+    with torch.cuda.device(dev):
+        batch = DeviceBatch(lps, [torch.as_tensor(np.asarray(x).reshape(-1).astype(np.int32)) for x in labs])
+        status = batch.run(raise_on_error=False)
+    written, first_bad = [], None
+    for (_, _, bf), (p, l, s), st in zip(todo, batch.results(), status.tolist()):
+        if st != 0:
+            first_bad = first_bad if first_bad is not None else (bf, st)
+            continue
         try:
             np.savez(bf, best_path=p.cpu().numpy(), best_labels=l.cpu().numpy(), best_scores=s.cpu().numpy())
         except BaseException:
             if os.path.exists(bf):
                 os.unlink(bf)
             raise
-    return [bf for _, _, bf in todo]
+        written.append(bf)
+    if first_bad is not None:
+        _lib.check(first_bad[1], f"best_path -> {first_bad[0]}")
+    return written
 
 
 # ------------------------------------------------------------------------------------------

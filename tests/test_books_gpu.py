@@ -197,3 +197,118 @@ def test_cfg5_stress_lattice_at_full_size_properties(beam):
     assert np.float32(chain).view(np.int32) == np.float32(b.total[0]).view(np.int32)
     del b, lps, labs
     torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------
+# round 3: the input classes around the green suite
+# ------------------------------------------------------------------------------------------
+def _lattice_with_neg_inf(T, S, V, seed, frac=0.10):
+    """hash log-probs with `frac` of the entries -inf (masked CTC posteriors: legal input, align.py:67-85 tracks the live
+    set explicitly), column 0 kept finite in most frames so that paths survive"""
+    lp = O.hash_logprobs_c(T, V, seed).copy()
+    rng = np.random.default_rng(seed)
+    lp[rng.random(lp.shape) < frac] = -np.inf
+    return lp, O.hash_labels(S, V, seed)
+
+
+def _compare(b, k, want, tag):
+    assert np.array_equal(b.path[k].cpu().numpy(), want[0]), f"{tag}: best_path differs"
+    assert np.array_equal(b.best_labels[k].cpu().numpy(), want[1]), f"{tag}: best_labels differ"
+    assert np.array_equal(b.best_scores[k].cpu().numpy().view(np.int32), want[2].view(np.int32)), f"{tag}: best_scores differ"
+    assert np.float32(b.total[k]).view(np.int32) == np.float32(want[3]).view(np.int32), f"{tag}: total differs"
+
+
+@pytest.mark.parametrize("beam", [2000, 5000, None])
+def test_wide_band_with_neg_inf_log_probs_is_answered(beam):
+    """Bands wider than the exact kernels' 1009-position ring whose log-probs hold -inf: the reference answers them
+    (align.py:67-85), so KA_MODE_AUTO must too (the tiled form declines, ka_batch_finish hands the lattice to the generic
+    kernels); only the explicit KA_MODE_TILED reports KA_ERR_NONFINITE (-7).  One launch mixes a finite wide lattice, two
+    with -inf and a narrow one with -inf (redone by the exact kernels inside the launch): indices must not get mixed up."""
+    import torch
+    from kokoro_align_amd.align import DeviceBatch
+    shapes = [(6000, 3000, 64, 41, 0.0), (6000, 3000, 64, 42, 0.10), (2500, 400, 64, 43, 0.10), (5000, 2600, 64, 44, 0.10)]
+    L_max = 2 * 3000 + 1
+    bm = beam if beam else 2 * L_max + 2
+    host = [_lattice_with_neg_inf(T, S, V, seed, frac) for T, S, V, seed, frac in shapes]
+    want = []
+    for lp, lab in host:
+        try:
+            want.append(O.ctc_best_path_c(lp, lab, bm, 4, return_total=True))
+        except ValueError:
+            want.append(None)
+    assert sum(w is not None for w in want) >= 3, "the case must exercise paths, not only empty beams"
+    lps = [torch.from_numpy(lp).cuda() for lp, _ in host]
+    labs = [torch.from_numpy(np.asarray(lab, np.int32)).cuda() for _, lab in host]
+    eng = _engine()
+    try:
+        for mode in ("auto", "auto+parallel"):
+            _set(eng, mode)
+            b = DeviceBatch(lps, labs, bm)
+            st = b.run(raise_on_error=False)
+            for k, w in enumerate(want):
+                if w is None:
+                    assert st[k] == -1, (mode, k, st[k])
+                else:
+                    assert st[k] == 0, (mode, k, st[k])
+                    _compare(b, k, w, f"{mode} beam {bm} lattice {k}")
+        # host buffers in, host buffers out (the boundary's KA_MEM_HOST path goes through the same hand-over)
+        _set(eng, "auto")
+        import kokoro_align_amd as ka
+        if want[1] is not None:
+            p, l, s = ka.ctc_best_path(host[1][0], host[1][1], beam_size=bm, verbose=False)
+            assert np.array_equal(p, want[1][0]) and np.array_equal(l, want[1][1]) and np.array_equal(s.view(np.int32), want[1][2].view(np.int32))
+        # the explicit tiled form has no answer for the wide ones with -inf and says so
+        _set(eng, "tiled")
+        b = DeviceBatch(lps, labs, bm)
+        st = b.run(raise_on_error=False)
+        assert st[0] == 0 and st[1] == -7 and st[3] == -7, st
+        _compare(b, 0, want[0], "tiled, finite lattice")
+        if want[2] is not None:
+            assert st[2] == 0
+            _compare(b, 2, want[2], "tiled, narrow lattice redone exactly")
+    finally:
+        _set(eng, "auto")
+
+
+def test_cfg2_whole_lattice_50k_frames_vs_oracle():
+    """T = 50000, S = 5000, beam_size >= 2L: BASELINE configs[1]'s lattice without a band (5e8 cells, 40 tiles
+    alive for all 50000 frames) against the C oracle, bit for bit - the largest unbanded case the oracle's back-pointer
+    array (T x L bytes = 500 MB) allows; configs[4]'s 5e10 cells are covered by properties above."""
+    from kokoro_align_amd import workloads as W
+    from kokoro_align_amd.align import DeviceBatch
+    c = W.CFG2
+    T, S, V = c["T"], c["S"], c["V"]
+    L = 2 * S + 1
+    lps, labs = W.device_book([(T, S)], V=V, seed0=0)
+    want = O.ctc_best_path_c(O.hash_logprobs_c(T, V, 0), O.hash_labels(S, V, 0), 2 * L + 2, 4, return_total=True)
+    eng = _engine()
+    try:
+        for mode in ("auto", "tiled"):
+            _set(eng, mode)
+            b = DeviceBatch(lps, labs, 2 * L + 2)
+            b.run()
+            _compare(b, 0, want, f"{mode}, whole 50000 x 10001 lattice")
+    finally:
+        _set(eng, "auto")
+
+
+def test_meian_book_with_the_hand_off_self_check_on(books_on_device):
+    """ka_engine_set_verify(1): the halo region starts as a NaN sentinel and every packet a tile consumes is checked against
+    it - a packet read before it was written gives KA_ERR_INTERNAL (-8).  The Meian book (120 chapters, ~2600 tiles, every
+    hand-off of the pipeline) must come through with status 0 and the oracle's paths; verify 2 (full drain before every
+    publish) must give the same."""
+    from kokoro_align_amd.align import DeviceBatch
+    lps, labs = books_on_device("meian")
+    want = _oracle("meian")
+    eng = _engine()
+    try:
+        for flags in (1, 3):
+            _set(eng, "tiled")
+            eng.set_verify(flags)
+            b = DeviceBatch(lps, labs)
+            st = b.run(raise_on_error=False)
+            assert not (st != 0).any(), (flags, sorted(set(st[st != 0].tolist())))
+            _check_against_oracle(b, want)
+    finally:
+        eng.set_verify(0)
+        _set(eng, "auto")

@@ -114,3 +114,37 @@ def test_persistent_lstm_many_tiles_and_empty_segments():
     b = lstm_logits_device(model, data, np.cumsum(lens), persistent=False)
     assert a.shape == b.shape == (int(lens.sum()), 39)
     np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=1e-4)
+
+
+def test_best_path_stage_keeps_per_file_progress_when_a_chapter_fails(tmp_path):
+    """run_example.py:248-254 loops the files: the `*.best_path.npz` written before a failing chapter stay written and are
+    skipped on the rerun.  Here all chapters are ONE launch, so the stage writes every chapter whose status is 0 and THEN
+    raises what the reference's best_path() raises for the first bad one (ValueError, align.py:101: empty beam)."""
+    import torch
+    from kokoro_align_amd import pipeline
+    voca_txt = g4()["voca_txt"]
+    logits, voca, out = [], [], []
+    for i, (T, reps) in enumerate([(900, 1), (700, 1), (20, 6), (1100, 1), (800, 1)]):   # chapter 2: 20 frames for ~600 phonemes
+        base = str(tmp_path / f"ch{i:02d}")
+        with pipeline.open_index_data_for_write(base + ".logits.npz") as w:
+            w.write(O.hash_logprobs(T, 39, 900 + i) + np.float32(4.0))
+        with open(base + ".voca.txt", "wt") as f:
+            f.write(voca_txt * reps)
+        logits.append(base + ".logits.npz"); voca.append(base + ".voca.txt"); out.append(base + ".best_path.npz")
+    with pytest.raises(ValueError, match="argmax of an empty sequence"):
+        pipeline.best_path_files(logits, voca, out)
+    assert [os.path.exists(f) for f in out] == [True, True, False, True, True]
+    from kokoro_align_amd.transcript import read_transcript
+    for k in (0, 1, 3, 4):
+        with np.load(logits[k]) as f:
+            lg = f["data"]
+        c = lg - np.mean(lg, axis=-1, keepdims=True)
+        want = O.ctc_best_path_c(c - np.log(np.sum(np.exp(c), axis=-1, keepdims=True)), read_transcript(voca[k]))
+        with np.load(out[k]) as f:
+            assert np.array_equal(f["best_path"], want[0]) and np.array_equal(f["best_labels"], want[1])
+    # the rerun skips the four that exist and fails on the same chapter again, writing nothing
+    before = {f: os.path.getmtime(f) for f in out if os.path.exists(f)}
+    with pytest.raises(ValueError):
+        pipeline.best_path_files(logits, voca, out)
+    assert before == {f: os.path.getmtime(f) for f in out if os.path.exists(f)} and not os.path.exists(out[2])
+    torch.cuda.synchronize()

@@ -1,10 +1,9 @@
 #!/usr/bin/env python3
-"""Where the tiles of a lattice spend their time (KA_TP_VERIFY=4): per tile, frames, alive time, time waiting for the
-tile below, ns per frame while not waiting.   KA_TP_VERIFY=4 python tools/tile_stats.py [T S V beam]"""
+"""Where the tiles of a lattice spend their time (ka_engine_set_verify(4)): per tile, frames, alive time, time waiting for the
+tile below, ns per frame while not waiting.   python tools/tile_stats.py [T S V beam]"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("KA_TP_VERIFY", "4")
 import numpy as np
 import torch
 from kokoro_align_amd import workloads as W
@@ -14,6 +13,7 @@ lps, labs = W.device_book([(T, S)], V=V, seed0=0)
 b = DeviceBatch(lps, labs, beam)
 b.engine.set_mode("tiled")
 b.engine.set_profiling(True)
+b.engine.set_verify(4)
 b.run(); b.run()
 print("forward_ms", b.engine.last_kernel_ms()["forward"])
 out = np.zeros((4096, 8), np.uint64)
@@ -32,3 +32,4 @@ simd = collections.Counter(((int(r[6]) >> 48) & 0xf, (int(r[6]) >> 45) & 7, (int
 cu = collections.Counter(k[:3] for k in simd.elements())
 print("tiles per SIMD (max):", max(simd.values()), " tiles per CU (max):", max(cu.values()), " distinct CUs:", len(cu))
 b.engine.set_mode("auto")
+b.engine.set_verify(0)
