@@ -53,6 +53,11 @@ const char *ka_last_error(void);
  * pinned staging and timing events for ONE device.  device = HIP ordinal. */
 int ka_engine_create(int32_t device, ka_engine **out);
 void ka_engine_destroy(ka_engine *e);
+/* A HIP stream (hipStream_t, non-blocking) for launches that should run beside others: one engine + one such stream per
+ * host thread lets the forward pass of one launch overlap the backtrace of another (kokoro_align_amd.streams).  Streams
+ * created one after the other land on different hardware queues while the runtime has any to spare (4 per device). */
+int ka_stream_create(int32_t device, void **stream);
+int ka_stream_destroy(int32_t device, void *stream);
 /* pre-size the workspace so that later calls do not allocate (optional) */
 int ka_engine_reserve(ka_engine *e, size_t workspace_bytes);
 /* device-workspace bytes one batch call needs (back-pointers dominate: 256 B per frame) */

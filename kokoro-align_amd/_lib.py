@@ -33,7 +33,7 @@ EXPORTS = [
     "ka_hash_logprobs_batch_f32", "ka_hash_labels_batch_i32", "ka_engine_set_mode", "ka_lstm_step_f32",
     "ka_lstm_layer_f32", "ka_window_energy_f32", "ka_stft_frames_f32", "ka_power_f32", "ka_power_to_db_f32",
     "ka_debug_tile_stats", "ka_engine_set_backtrace", "ka_debug_chunk_entries", "ka_debug_plan_tiles",
-    "ka_engine_set_verify",
+    "ka_engine_set_verify", "ka_stream_create", "ka_stream_destroy",
 ]
 
 
@@ -94,6 +94,10 @@ def load_library():
     L.ka_engine_set_mode.argtypes = [vp, i32]
     L.ka_engine_set_backtrace.restype = ctypes.c_int
     L.ka_engine_set_backtrace.argtypes = [vp, i32]
+    L.ka_stream_create.restype = ctypes.c_int
+    L.ka_stream_create.argtypes = [i32, pp]
+    L.ka_stream_destroy.restype = ctypes.c_int
+    L.ka_stream_destroy.argtypes = [i32, vp]
     L.ka_engine_set_verify.restype = ctypes.c_int
     L.ka_engine_set_verify.argtypes = [vp, i32]
     L.ka_engine_set_profiling.restype = ctypes.c_int

@@ -320,6 +320,27 @@ void ka_engine_destroy(ka_engine *e)
     delete e;
 }
 
+int ka_stream_create(int32_t device, void **stream)
+{
+    if (!stream) return fail(KA_ERR_BAD_ARGS, "ka_stream_create: stream is NULL");
+    DeviceGuard guard;
+    KA_HIP(guard.enter(device));
+    hipStream_t s = nullptr;
+    KA_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void *)s;
+    return KA_OK;
+}
+
+int ka_stream_destroy(int32_t device, void *stream)
+{
+    if (!stream) return KA_OK;
+    DeviceGuard guard;
+    KA_HIP(guard.enter(device));
+    KA_HIP(hipStreamSynchronize((hipStream_t)stream));
+    KA_HIP(hipStreamDestroy((hipStream_t)stream));
+    return KA_OK;
+}
+
 int ka_engine_reserve(ka_engine *e, size_t workspace_bytes)
 {
     if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");

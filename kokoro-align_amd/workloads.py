@@ -43,6 +43,50 @@ def meian_book():
     return "Meian stand-in (16.66 h)", book_shapes(5_170_000, 120, 2)
 
 
+# example.json of the reference: the 14 datasets with "enabled": true and their `totaltime` (h:mm:ss), in file order -
+# the unit of work of `python run_example.py` without --dataset (run_example.py:283-304 loops them).  63.95 hours.
+CORPUS_DATASETS = (
+    ("meian-by-soseki-natsume", "16:39:29"), ("kokoro-by-soseki-natsume", "08:46:41"), ("inakakyoshi-by-katai-tayama", "08:13:26"),
+    ("nowaki-by-soseki-natsume", "4:40:49"), ("kusamakura-by-soseki-natsume", "04:27:35"), ("botchan-by-soseki-natsume-2", "04:26:27"),
+    ("gan-by-ogai-mori", "03:41:31"), ("umareizuru-nayami-by-takeo-arishima", "2:43:12"), ("garasudono-uchi-by-natsume-soseki", "2:39:53"),
+    ("eijitsu-syohin-by-soseki-natsume", "2:33:54"), ("futon-by-katai-tayama", "2:28:58"), ("kouyahijiri-by-kyoka-izumi", "2:06:23"),
+    ("gongitsune-by-nankichi-niimi", "0:15:42"), ("caucasus-no-hagetaka-by-yoshio-toyoshima", "0:13:04"),
+)
+FRAMES_PER_SECOND = 22050.0 / 256.0      # preprocess.py:102-104 (sample rate / hop length)
+CORPUS_SEED0 = 20000
+
+
+def _seconds(hms):
+    h, m, s = (int(x) for x in hms.split(":"))
+    return 3600 * h + 60 * m + s
+
+
+def corpus():
+    """The whole of example.json as the alignment step sees it: [(dataset id, [(T, S), ...])] for the 14 enabled
+    datasets.  Chapter counts are not in example.json (they are the MP3s of each LibriVox zip): the two books whose
+    stand-ins exist keep theirs (120 and 64 chapters, 8.3 minutes on average) and the others get one chapter per 8.25
+    minutes of audio, lengths by the recipe of book_shapes (weights uniform in [0.4, 3.0], 20k..160k frames, S = 0.14 T);
+    the two recordings of a quarter of an hour are single files.  ~460 lattices, ~19.8 M frames."""
+    out = []
+    for k, (name, total) in enumerate(CORPUS_DATASETS):
+        frames = int(_seconds(total) * FRAMES_PER_SECOND)
+        if name.startswith("meian"):
+            shapes = meian_book()[1]
+        elif name.startswith("kokoro-by"):
+            shapes = kokoro_book()[1]
+        elif frames < 160000:
+            shapes = [(frames, int(0.14 * frames))]
+        else:
+            shapes = book_shapes(frames, max(1, round(_seconds(total) / 60.0 / 8.25)), 100 + k)
+        out.append((name, shapes))
+    return out
+
+
+def corpus_seed0(dataset_index):
+    """hash seed of chapter 0 of dataset `dataset_index` of corpus(): chapter i uses seed0 + i"""
+    return CORPUS_SEED0 + 1000 * dataset_index
+
+
 def device_book(shapes, V=V_MODEL, seed0=BOOK_SEED0, device="cuda"):
     """Hash-generated log-probs and labels of every chapter, resident on the device.
     Returns (log_probs list, labels list)."""

@@ -4,8 +4,9 @@
 G engines, each with its own stream and workspace, each owning B/G cfg2 lattices; G host threads loop enqueue + finish K
 times, thread g started g/G of a period late so that the phases interleave.  Compared with one engine over all B lattices.
 
-    python tools/overlap_probe.py [B] [K]
+    python tools/overlap_probe.py [B] [K] [G:stagger_ms,...]
 """
+import ctypes
 import json
 import os
 import sys
@@ -34,15 +35,22 @@ torch.cuda.synchronize()
 
 def run(G, stagger_ms, period_ms=72.0):
     n = B // G
-    batches, streams = [], []
+    batches, streams, raw = [], [], []
     for g in range(G):
         b = DeviceBatch([lps[i] for i in range(g * n, (g + 1) * n)], [labs[i] for i in range(g * n, (g + 1) * n)], 1000, 4)
         b.engine = _lib.Engine(0)
-        b.engine.set_mode("wave")
-        b.engine.set_backtrace("serial")
+        b.engine.set_mode(os.environ.get("PROBE_MODE", "wave"))
+        b.engine.set_backtrace(os.environ.get("PROBE_BACKTRACE", "serial"))
+        b.engine.set_profiling(os.environ.get("PROBE_PROFILING", "0") == "1")
         b.engine.reserve(b.workspace_bytes() + (1 << 20))
         batches.append(b)
-        streams.append(torch.cuda.Stream(device=dev))
+        if os.environ.get("PROBE_OWN_STREAMS", "1") == "1":
+            h = ctypes.c_void_p()
+            assert lib.ka_stream_create(0, ctypes.byref(h)) == 0
+            raw.append(h)
+            streams.append(torch.cuda.ExternalStream(h.value, device=dev))
+        else:
+            streams.append(torch.cuda.current_stream(dev) if g == 0 and os.environ.get('PROBE_NULL_STREAM', '1') == '1' else torch.cuda.Stream(device=dev))
     for b, s in zip(batches, streams):      # warm-up, one after the other
         with torch.cuda.stream(s):
             b.run()
@@ -71,18 +79,19 @@ def run(G, stagger_ms, period_ms=72.0):
     el = max(done) - t0
     ok = all(int(b.path[0][-1]) == 2 * S for b in batches)
     res = {"engines": G, "lattices_each": n, "stagger_ms": stagger_ms, "steps": K, "ms_per_step_all": el / K * 1e3,
-           "frames_per_s": B * T * K / el, "ends_ok": ok}
+           "frames_per_s": n * G * T * K / el, "ms_per_8192": el / K * 1e3 * 8192 / (n * G), "ends_ok": ok}
     print(json.dumps(res), flush=True)
     for b in batches:
         b.engine.close()
+    for h in raw:
+        lib.ka_stream_destroy(0, h)
     del batches
     torch.cuda.empty_cache()
     return res
 
 
-run(1, 0)
-run(2, 0)
-run(2, 36)
-run(4, 0)
-run(4, 18)
-run(8, 9)
+plan = [(1, 0), (2, 0), (2, 36), (4, 0), (4, 18), (8, 9)]
+if len(sys.argv) > 3:     # "G:stagger_ms,G:stagger_ms,..."
+    plan = [tuple(int(x) for x in item.split(":")) for item in sys.argv[3].split(",")]
+for G, stagger in plan:
+    run(G, stagger)

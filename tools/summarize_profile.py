@@ -45,6 +45,7 @@ if kt:
         {"kernel": k, "grid_threads": g, "calls": len(v), "avg_ms": sum(v) / len(v), "min_ms": min(v), "max_ms": max(v)}
         for (k, g), v in sorted(per.items())]
 pmc = {}
+sq_ms = collections.defaultdict(list)      # dispatch durations inside the SQ / GRBM counter pass (for the clock under load)
 for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
     f = one(f"{name}/*/*counter_collection.csv")
     if not f:
@@ -55,6 +56,15 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
             continue
         key = (k, int(r["Grid_Size"]))
         pmc.setdefault(key, collections.defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if name == "pmc_sq" and r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r.get("Start_Timestamp") and r.get("End_Timestamp"):
+            sq_ms[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+if not sq_ms:
+    kt_sq = one("pmc_sq/*/*kernel_trace.csv")
+    if kt_sq:
+        for r in csv.DictReader(open(kt_sq)):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            grid = int(r["Grid_Size"]) if "Grid_Size" in r else int(r.get("Grid_Size_X", 0))
+            sq_ms[(k, grid)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 rows = []
 for (k, g), c in sorted(pmc.items()):
     rows.append({"kernel": k, "grid_threads": g, "counters_per_dispatch": {n: sum(v) / len(v) for n, v in c.items()}})
@@ -90,15 +100,23 @@ for r in rows:
                     job += cc.get("FETCH_SIZE", 0.0) * 2048 + cc.get("WRITE_SIZE", 0.0) * 1024
             frames = lattices * frames_per_lattice
             valu = c.get("SQ_INSTS_VALU")
+            # shader clock while the forward kernel ran: GRBM_GUI_ACTIVE counts busy cycles of all 8 XCDs
+            clock = None
+            dur = sq_ms.get((r["kernel"], r["grid_threads"]))
+            if dur and c.get("GRBM_GUI_ACTIVE"):
+                clock = c["GRBM_GUI_ACTIVE"] / 8.0 / (sum(dur) / len(dur) * 1e6)
+            summary["forward_clock_ghz"] = clock
             summary["job_hbm_bytes_per_step"] = job
             summary["forward_valu_per_frame"] = valu / frames if valu else None
             with open(os.path.join(out_dir, "pmc_traffic.json"), "wt") as f:
                 json.dump({"lattices": lattices, "hbm_bytes_per_launch": read_b + write_b, "tag": tag,
                            "job_hbm_bytes_per_step": job,
                            "forward_valu_per_frame": valu / frames if valu else None,
+                           "forward_clock_ghz": clock,
                            "note": "FETCH_SIZE*1024*2 + WRITE_SIZE*1024 of forward_ck_kernel<4,false>, one launch; "
                                    "job = the same sum over the step's forward, backtrace and gather launches; "
-                                   "forward_valu_per_frame = SQ_INSTS_VALU of the forward launch / frames"}, f)
+                                   "forward_valu_per_frame = SQ_INSTS_VALU of the forward launch / frames; "
+                                   "forward_clock_ghz = GRBM_GUI_ACTIVE / 8 XCDs / the launch's duration in the same counter pass"}, f)
 bj = os.path.join(src, "bench_under_rocprof.json")
 if os.path.exists(bj):
     try:
