@@ -101,15 +101,34 @@ __device__ __forceinline__ void tp_mask_toggle(TpMasks &mk, int32_t rel)
     mk.m2 ^= k == 2 ? bit : 0ull;
     mk.m3 ^= k == 3 ? bit : 0ull;
 }
-// -inf into the cell at tile-relative position rel (0..255): S = {cell 0, 2, 1, 3} of lane rel >> 2
+// -inf into the cell at tile-relative position rel (0..255): S = {cell 0, 2, 1, 3} of lane rel >> 2.  ONE v_cndmask behind
+// a two-level scalar branch INSIDE one asm statement (6 instructions executed; as C++ - four selects on masks picked by
+// s_cselect, or a switch whose arms are asm statements - hipcc made 24 to 35 of it, with copies at the merges).
 __device__ __forceinline__ void tp_kill(f32x4 &S, uint32_t rel, float NINF)
 {
     const uint64_t m = 1ull << (rel >> 2);
-    const uint32_t k = rel & 3u;
-    S[0] = select_by_mask(S[0], NINF, k == 0 ? m : 0ull);
-    S[2] = select_by_mask(S[2], NINF, k == 1 ? m : 0ull);
-    S[1] = select_by_mask(S[1], NINF, k == 2 ? m : 0ull);
-    S[3] = select_by_mask(S[3], NINF, k == 3 ? m : 0ull);
+    float c0 = S[0], c2 = S[1], c1 = S[2], c3 = S[3];
+    asm volatile("s_bitcmp1_b32 %[rel], 1\n\t"
+                 "s_cbranch_scc1 .Lka_k23_%=\n\t"
+                 "s_bitcmp1_b32 %[rel], 0\n\t"
+                 "s_cbranch_scc1 .Lka_k1_%=\n\t"
+                 "v_cndmask_b32 %[c0], %[c0], %[ninf], %[m]\n\t"
+                 "s_branch .Lka_ke_%=\n"
+                 ".Lka_k1_%=:\n\t"
+                 "v_cndmask_b32 %[c1], %[c1], %[ninf], %[m]\n\t"
+                 "s_branch .Lka_ke_%=\n"
+                 ".Lka_k23_%=:\n\t"
+                 "s_bitcmp1_b32 %[rel], 0\n\t"
+                 "s_cbranch_scc1 .Lka_k3_%=\n\t"
+                 "v_cndmask_b32 %[c2], %[c2], %[ninf], %[m]\n\t"
+                 "s_branch .Lka_ke_%=\n"
+                 ".Lka_k3_%=:\n\t"
+                 "v_cndmask_b32 %[c3], %[c3], %[ninf], %[m]\n"
+                 ".Lka_ke_%=:"
+                 : [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [c3] "+v"(c3)
+                 : [rel] "s"(rel), [m] "s"(m), [ninf] "v"(NINF)
+                 : "scc");
+    S = f32x4{c0, c2, c1, c3};
 }
 // state of a lane: S = {cell 0, cell 2, cell 1, cell 3} = {blank, blank, label, label} - the two blanks and the two labels
 // are register pairs (v_pk_add_f32 of the emissions), and the four registers as they lie ARE the halo packet
@@ -186,8 +205,23 @@ __device__ __forceinline__ bool tp_wait_progress(gu32w_t word, uint32_t need, ui
 template <int M, bool ZL>
 struct TpTile {
     // wave-uniform description of the tile and its lattice
-    uint32_t T, L, B, dq, dr;   // (B/2 and the band-step threshold are derived where they are needed: scalar registers are scarce here)
-    __device__ __forceinline__ uint32_t thr_real() const { return dq != 0 ? 0u : T; }
+    uint32_t T, L, B, dq, dr;
+    // The band (align.py:64-65) per BLOCK of 32 frames, not per frame: q0 / r0 = floor(L tb / T) and the remainder at the
+    // block's first frame tb, advanced by (32 L) / T, (32 L) % T per block; per block the lanes work out, 34 frames at once,
+    // which positions of THIS tile enter or leave the band at which frame (KE / KL) and `ev` gets bit F set when frame
+    // tb+F has any to kill.  The common frame pays one s_bitcmp1 + branch, and a tile pays nothing at all for
+    // the band steps that do not touch it - 3 of 5 for a 1000-wide band, whose edges are inside a tile for 2 x 256 of the
+    // ~1250 steps the tile lives through.  (Rounds 1-2 stepped a Bresenham remainder in every frame and ran ~40 scalar
+    // instructions at every step, relevant or not: 161 cycles per frame in cfg2 against 105 where the band never moves.)
+    uint32_t q0, r0, dq32, dr32, ev;
+    uint32_t KL, KE;        // per lane (VGPRs): the cells to kill, lane l <-> the band step after frame tb - 1 + l (tp_band_block)
+    float inv_T;
+    __device__ __forceinline__ uint32_t lo_of(uint32_t q) const
+    {
+        const int32_t d = (int32_t)q - (int32_t)(B >> 1);
+        return (uint32_t)(d > 0 ? d : 0);
+    }
+    __device__ __forceinline__ uint32_t hi_of(uint32_t lo) const { return (L - lo < B) ? L : lo + B; }
     int32_t base, t_in, t_end;
     const char *lp;
     size_t ld;
@@ -198,9 +232,6 @@ struct TpTile {
     char *ck;               // checkpoint k (scores after frame 32 (k + 1) - 1) at ck + k * ck_pitch
     uint32_t ck_pitch;
     uint32_t ck_off;        // per lane: ((base + 4 lane) & ck_mask) * 4
-    // band state of the frame being computed
-    uint32_t q, rem, lo, hi, thr;
-    uint32_t kill_from, kill_to;   // positions that left the band in the previous frame's step and die after this frame (rule ii)
     // per lane
     f32x4 S;
     int la0, la1;           // 4 * label of cells 1 and 3
@@ -241,41 +272,18 @@ __device__ __forceinline__ void tp_frame(TpTile<M, ZL> &c, uint32_t t, float (&H
         mb[0] = cell_blank_max<M>(b0, H[0], H[2]);
         const f32x2 sl = ml + cur.E, sb = mb + f32x2{cur.e0, cur.e0};
         c.S = f32x4{sb[0], sb[1], sl[0], sl[1]};
-        // band of the next frame (align.py:64-65), advanced Bresenham-style.  The band is enforced by KILLING single cells,
-        // not by masking all of them: a cell above hi collects "leaked" scores from the live cells under it and must hold
-        // -inf at the moment it enters the band (rule i: killed in the frame before the step); a cell that has dropped
-        // below lo was live in the last frame of the old band, is still computed in the first frame of the new one and
-        // must be dead after it (rule ii: killed one frame after the step) - from then on it only reads cells below
-        // itself, which are dead, and stays -inf by itself.  Only positions inside this tile cost anything.
-        c.rem += c.dr;
-        if (__builtin_expect(c.rem >= c.thr, 0)) {
+        // The band is enforced by KILLING single cells, not by masking all of them: a cell above hi collects "leaked" scores
+        // from the live cells under it and must hold -inf at the moment it enters the band (rule i: the positions
+        // [hi(t), hi(t+1)) are killed after frame t); a cell that has dropped below lo was live in the last frame of the old
+        // band, is still computed in the first frame of the new one and must be dead after it (rule ii: the positions
+        // [lo(t-1), lo(t)) are killed after frame t) - from then on it only reads cells below itself, which are dead, and
+        // stays -inf by itself.  `ev` marks the frames in which either range meets this tile (tp_band_block).
+        if (__builtin_expect((c.ev >> F) & 1u, 0)) {
             asm volatile("" ::: "memory");
-            c.thr = c.thr_real();
-            const uint32_t tile_lo = (uint32_t)c.base, tile_hi = (uint32_t)c.base + kTpTile;
-            if (c.kill_to > c.kill_from) {   // rule ii for the step of the previous frame
-                for (uint32_t p = c.kill_from; p < c.kill_to; ++p) tp_kill(c.S, p - tile_lo, NINF);
-                c.kill_to = c.kill_from = 0;
-            }
-            if (c.rem >= c.thr_real()) {
-                c.q += c.dq;
-                if (c.rem >= c.T) { c.rem -= c.T; ++c.q; }
-                if (t + 1 != c.T) {
-                    const int32_t dlo = (int32_t)c.q - (int32_t)(c.B >> 1);
-                    const uint32_t nlo = (uint32_t)(dlo > 0 ? dlo : 0);
-                    const uint32_t nhi = (c.L - nlo < c.B) ? c.L : nlo + c.B;
-                    // rule i: what enters at the top, now
-                    for (uint32_t p = c.hi > tile_lo ? c.hi : tile_lo; p < (nhi < tile_hi ? nhi : tile_hi); ++p) tp_kill(c.S, p - tile_lo, NINF);
-                    // rule ii: what leaves at the bottom, after the next frame
-                    const uint32_t a = c.lo > tile_lo ? c.lo : tile_lo, b2 = nlo < tile_hi ? nlo : tile_hi;
-                    if (b2 > a) {
-                        c.kill_from = a;
-                        c.kill_to = b2;
-                        c.thr = 0;   // frame t+1 must come through here again
-                    }
-                    c.lo = nlo;
-                    c.hi = nhi;
-                }
-            }
+            // what to kill was worked out for the whole block (tp_band_block): first tile-relative position | count << 16
+            const uint32_t k2 = (uint32_t)__builtin_amdgcn_readlane((int)c.KL, F), k1 = (uint32_t)__builtin_amdgcn_readlane((int)c.KE, F + 1);
+            for (uint32_t r = k2 & 0xffffu, e = r + (k2 >> 16); r < e; ++r) tp_kill(c.S, r, NINF);   // rule ii: left the band before this frame
+            for (uint32_t r = k1 & 0xffffu, e = r + (k1 >> 16); r < e; ++r) tp_kill(c.S, r, NINF);   // rule i: enters it after this frame
         }
     }
     // the three cells below every lane's first cell, for frame t+1 (lane 0: from the packet of the tile below)
@@ -291,6 +299,49 @@ __device__ __forceinline__ void tp_frame(TpTile<M, ZL> &c, uint32_t t, float (&H
     if (live) *(__attribute__((address_space(3))) f32x4 *)(uintptr_t)(c.lds_stage + F * 16) = c.S;
     cur = nxt;
     nxt = far;
+}
+
+// Band bookkeeping of the block that starts at frame tb (c.q0 / c.r0 are that frame's floor(L tb / T) and remainder): lane l
+// works out floor(L t / T) for frame t = tb - 1 + l (l = 0 .. 33 are used) - x / T for x < 63 T < 2^32 by a float estimate
+// and one correction each way, as in backtrace_rc_kernel - and, for the band step between its frame and the next one,
+// which positions enter at the top (rule i) or leave at the bottom (rule ii) inside this tile (first position and count,
+// packed).  A rule-i step after frame t is dealt with in frame t, a rule-ii step after frame t in frame t+1: bit F of c.ev <=>
+// frame tb + F visits the band code, which reads its two kill words with v_readlane.  ~45 vector and a dozen scalar instructions per block; nothing per frame.
+template <int M, bool ZL>
+__device__ __forceinline__ void tp_band_block(TpTile<M, ZL> &c, uint32_t tb, int lane)
+{
+    const uint32_t l1 = lane > 0 ? (uint32_t)lane - 1u : 0u;
+    const uint32_t x = c.r0 + l1 * c.dr;
+    uint32_t qe = (uint32_t)((float)x * c.inv_T);
+    qe -= (qe * c.T > x) ? 1u : 0u;
+    qe += (x - qe * c.T >= c.T) ? 1u : 0u;
+    uint32_t qa = c.q0 + l1 * c.dq + qe;
+    const uint32_t q_before = tb == 0 ? c.q0 : (c.r0 >= c.dr ? c.q0 - c.dq : c.q0 - c.dq - 1u);   // frame tb-1 (block 0: no step into frame 0)
+    qa = lane == 0 ? q_before : qa;
+    // floor(L (t+1) / T): the lane above's value (DPP wave_shl:1; lane 63 keeps its own, it is not used)
+    const uint32_t qn = (uint32_t)__builtin_amdgcn_update_dpp((int)qa, (int)qa, 0x130, 0xF, 0xF, false);
+    const uint32_t tile_lo = (uint32_t)c.base, tile_hi = (uint32_t)c.base + kTpTile;
+    const uint32_t lo_a = c.lo_of(qa), lo_n = c.lo_of(qn);
+    const uint32_t hi_a = c.hi_of(lo_a), hi_n = c.hi_of(lo_n);
+    const uint32_t t = tb - 1u + (uint32_t)lane;          // (lane 0 of block 0 wraps: its step is void, q_before == q0)
+    // rule ii: [lo(t), lo(t+1)) within the tile, killed after frame t+1 (bit l of ev, word read from lane F of KL)
+    const uint32_t la = lo_a > tile_lo ? lo_a : tile_lo, lb = lo_n < tile_hi ? lo_n : tile_hi;
+    const bool leave = la < lb;
+    c.KL = leave ? (la - tile_lo) | ((lb - la) << 16) : 0u;
+    // rule i: [hi(t), hi(t+1)) within the tile, killed after frame t (bit l-1 of ev, word read from lane F+1 of KE)
+    const uint32_t ea = hi_a > tile_lo ? hi_a : tile_lo, eb = hi_n < tile_hi ? hi_n : tile_hi;
+    const bool enter = ea < eb && t + 1u < c.T;
+    c.KE = enter ? (ea - tile_lo) | ((eb - ea) << 16) : 0u;
+    const uint64_t b_leave = __builtin_amdgcn_ballot_w64(leave), b_enter = __builtin_amdgcn_ballot_w64(enter);
+    c.ev = (uint32_t)b_leave | (uint32_t)(b_enter >> 1);
+}
+// one block further
+template <int M, bool ZL>
+__device__ __forceinline__ void tp_band_advance(TpTile<M, ZL> &c)
+{
+    c.q0 += c.dq32;
+    c.r0 += c.dr32;
+    if (c.r0 >= c.T) { c.r0 -= c.T; ++c.q0; }
 }
 
 // the frames of a block.  LDS byte addresses of this block's slot (A[0]) and the next one's (A[1]): row 0 + the lane's
@@ -385,17 +436,17 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
     c.lds_packets = lds_halo + kTpRing * kTpBlock * 16 + 16;   // (16 bytes of progress looks sit in between)
     c.lds_stage = lane == 63 ? c.lds_packets : c.lds_packets + kTpBlock * 16 + (uint32_t)lane * 16u;
     static_assert(kTpBlock * 16 + 62 * 16 + (kTpBlock - 1) * 16 + 16 <= kTpStageBytes, "publish staging");
-    // band of frame t_in (64-bit division once per tile; wave-uniform)
+    // band bookkeeping (64-bit divisions once per tile; wave-uniform): the tile's first block, and one block's advance
+    const auto uni = [](uint64_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v); };
     {
-        const uint64_t x = (uint64_t)c.L * (uint64_t)(uint32_t)c.t_in;
-        c.q = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x / c.T));
-        c.rem = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x % c.T));
-        const int32_t dlo = (int32_t)c.q - (int32_t)(c.B >> 1);
-        c.lo = (uint32_t)(dlo > 0 ? dlo : 0);
-        c.hi = (c.L - c.lo < c.B) ? c.L : c.lo + c.B;
-        c.kill_from = c.kill_to = 0;
-        c.thr = c.thr_real();
-        asm("" : "+s"(c.thr));
+        const uint64_t x = (uint64_t)c.L * (uint64_t)((uint32_t)c.t_in / kTpBlock * kTpBlock);
+        c.q0 = uni(x / c.T);
+        c.r0 = uni(x % c.T);
+        c.dq32 = uni(((uint64_t)c.L * kTpBlock) / c.T);
+        c.dr32 = uni(((uint64_t)c.L * kTpBlock) % c.T);
+        c.inv_T = 1.0f / (float)c.T;
+        c.ev = 0;
+        c.KL = c.KE = 0;
     }
     // labels of the lane's two label cells (positions base + 4 lane + 1, + 3); labx is zero padded past S
     {
@@ -487,19 +538,17 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
     // with a NaN pattern no score can have) no packet this tile is going to consume may still hold that pattern
     auto landed_block = [&](int32_t k) {
         const uint32_t slot = ring(k);
-        // (all reads first, then the sum: written as one accumulation chain hipcc waited for every read in turn -
-        //  1700 cycles per 16 frames, more than the frames themselves)
-        const uint32_t r = c.lds_rows + slot * kTpSlotBytes + (uint32_t)lane * 4u;
-        constexpr int kReads = !CONTIG ? kTpBlock : (kTpBlock * PITCH + 255) / 256;
-        float v[kReads];
+        // (all reads first, then the sum: written as one accumulation chain hipcc waited for every read in turn - 1700
+        //  cycles per 16 frames, more than the frames themselves.  16 bytes per lane and read: every KB the staging wrote
+        //  is log-probs - whole KBs are written, clamped to the lattice's last row - 8 or 5 reads instead of 32 or 20.)
+        const uint32_t r = c.lds_rows + slot * kTpSlotBytes + (uint32_t)lane * 16u;
+        constexpr int kReads = !CONTIG ? kTpSlotBytes / 1024 : kRowDmas;
+        f32x4 v[kReads];
 #pragma unroll
-        for (int j = 0; j < kReads; ++j) v[j] = lds_f32(r + j * 256);
+        for (int j = 0; j < kReads; ++j) v[j] = lds_f32x4(r + j * 1024);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int j = 0; j < kReads; ++j) {
-            const bool real = !CONTIG || j * 256 + 252 < kTpBlock * PITCH || j * 256 + lane * 4 < kTpBlock * PITCH;   // (past the block's last row: not a log-prob)
-            c.absum += real ? __builtin_fabsf(v[j]) : 0.0f;
-        }
+        for (int j = 0; j < kReads; ++j) c.absum += (__builtin_fabsf(v[j][0]) + __builtin_fabsf(v[j][1])) + (__builtin_fabsf(v[j][2]) + __builtin_fabsf(v[j][3]));
         if (verify & 1) {
             const int32_t sidx = k * kTpBlock + (lane & (kTpBlock - 1));
             const f32x4 h = lds_f32x4(c.lds_halo + slot * (kTpBlock * 16) + (uint32_t)(lane & (kTpBlock - 1)) * 16u);
@@ -565,6 +614,7 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
             H[1] = wave_shr1(hp[1], c.S[1]);
             H[2] = wave_shr1(hp[2], c.S[2]);
         }
+        tp_band_block(c, tb, lane);
         const bool partial = (int32_t)tb < c.t_in || (int32_t)(tb + kTpBlock) > c.t_end;
         if (!partial) {
             const unsigned long long fr0 = (verify & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -585,6 +635,7 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
             // (a partial block issued an unknown number of stores: its count stays 0, a lower bound, and the waits that
             //  cover it wait for a store or two more than they must)
         }
+        tp_band_advance(c);
     }
     // drain the staging loads still in flight (their registers are dead to the compiler after the loop and would be
     // reused while a load can still land in them).  No register operands here: nothing reads those registers again,
@@ -627,7 +678,9 @@ __device__ __forceinline__ void tp_run_tile(const Lattice &d, const TileTask &tk
     // ---- terminal state: the HIGHEST live position of frame T-1 (align.py:99-101), over the tiles alive then ----
     if ((uint32_t)c.t_end == c.T) {
         TpMasks mk;   // (the only full band mask of a tile's life: cells above hi may hold leaked scores)
-        tp_masks(mk, (int32_t)c.lo - c.base, (int32_t)c.hi - c.base);
+        const uint32_t q_last = c.L - (c.L + c.T - 1u) / c.T;   // floor(L (T-1) / T) = L - ceil(L / T)
+        const uint32_t lo_last = c.lo_of(q_last), hi_last = c.hi_of(lo_last);
+        tp_masks(mk, (int32_t)lo_last - c.base, (int32_t)hi_last - c.base);
         tp_mask_state(c.S, mk, NINF);
         const float cell[4] = {c.S[0], c.S[2], c.S[1], c.S[3]};
         unsigned long long key = 0;
