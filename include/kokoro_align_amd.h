@@ -151,6 +151,9 @@ int ka_engine_set_backtrace(ka_engine *e, int32_t how);
 /* Per-kernel timing of the LAST enqueued batch, measured with HIP events recorded on the
  * launch stream: ms[0] label prep, ms[1] forward DP, ms[2] backtrace walk, ms[3] output
  * gathers (best_labels / best_scores).  Enable before the call; costs one event per kernel. */
+/* Wavefronts per tile of the tiled form: 2 (default; ka_tiled2.hpp: one wavefront runs the frames, the other stages rows and
+ * halo packets, polls, publishes) or 1 (ka_tiled.hpp: one wavefront does both).  Results are identical. */
+int ka_engine_set_tile_waves(ka_engine *e, int32_t waves);
 /* Self-checks of the tiled form's hand-off, a combination of:
  *   1  the halo region is filled with a NaN sentinel before the launch and every packet a tile consumes is checked
  *      against it: a packet read before it was written gives the lattice KA_ERR_INTERNAL (tests)

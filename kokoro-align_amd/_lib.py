@@ -33,7 +33,7 @@ EXPORTS = [
     "ka_hash_logprobs_batch_f32", "ka_hash_labels_batch_i32", "ka_engine_set_mode", "ka_lstm_step_f32",
     "ka_lstm_layer_f32", "ka_window_energy_f32", "ka_stft_frames_f32", "ka_power_f32", "ka_power_to_db_f32",
     "ka_debug_tile_stats", "ka_engine_set_backtrace", "ka_debug_chunk_entries", "ka_debug_plan_tiles",
-    "ka_engine_set_verify", "ka_stream_create", "ka_stream_destroy",
+    "ka_engine_set_verify", "ka_stream_create", "ka_stream_destroy", "ka_engine_set_tile_waves",
 ]
 
 
@@ -47,7 +47,7 @@ def library_path():
 
 def build_library(force=False):
     """Compile the HIP library for gfx950 (cross-compiles without a GPU)."""
-    srcs = [os.path.join(_PKG, "csrc", f) for f in ("ka_engine.hip", "ka_kernels.hpp", "ka_tiled.hpp", "ka_parallel_bt.hpp")]
+    srcs = [os.path.join(_PKG, "csrc", f) for f in ("ka_engine.hip", "ka_kernels.hpp", "ka_tiled.hpp", "ka_tiled2.hpp", "ka_parallel_bt.hpp")]
     srcs.append(os.path.join(os.path.dirname(_PKG), "include", "kokoro_align_amd.h"))
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:
@@ -98,6 +98,8 @@ def load_library():
     L.ka_stream_create.argtypes = [i32, pp]
     L.ka_stream_destroy.restype = ctypes.c_int
     L.ka_stream_destroy.argtypes = [i32, vp]
+    L.ka_engine_set_tile_waves.restype = ctypes.c_int
+    L.ka_engine_set_tile_waves.argtypes = [vp, i32]
     L.ka_engine_set_verify.restype = ctypes.c_int
     L.ka_engine_set_verify.argtypes = [vp, i32]
     L.ka_engine_set_profiling.restype = ctypes.c_int
@@ -194,6 +196,10 @@ class Engine:
         """'auto' | 'serial' (chunk after chunk) | 'parallel' (every chunk at once; ka_parallel_bt.hpp)"""
         code = {"auto": 0, "serial": 1, "parallel": 2}[how] if isinstance(how, str) else int(how)
         check(self.lib.ka_engine_set_backtrace(self.handle, code), "ka_engine_set_backtrace")
+
+    def set_tile_waves(self, waves):
+        """Wavefronts per tile of the tiled form: 2 (default: one computes, one feeds) or 1."""
+        check(self.lib.ka_engine_set_tile_waves(self.handle, int(waves)), "ka_engine_set_tile_waves")
 
     def set_verify(self, flags):
         """Self-checks of the tiled form's hand-off (ka_engine_set_verify): 1 = sentinel-filled halos, every consumed packet

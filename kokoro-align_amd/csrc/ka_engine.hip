@@ -7,6 +7,7 @@
 #include "../../include/kokoro_align_amd.h"
 #include "ka_kernels.hpp"
 #include "ka_tiled.hpp"
+#include "ka_tiled2.hpp"
 #include "ka_parallel_bt.hpp"
 
 #include <algorithm>
@@ -187,6 +188,7 @@ struct ka_engine {
     std::vector<Redo> redo;
     int32_t last_V = 0, last_beam = 0, last_max_move = 0, last_mem = KA_MEM_DEVICE;
     int32_t verify = 0;                    // ka_engine_set_verify: self-checks of the tiled form's hand-off
+    int32_t tile_waves = 2;                // ka_engine_set_tile_waves: wavefronts per tile of the tiled form
     size_t dbg_entry = 0, dbg_entry_n = 0, dbg_map0 = 0, dbg_map0_bytes = 0;   // last batch, descriptor 0: chunk entries and chunk maps
     size_t dbg_tasks = 0, dbg_stats = 0, dbg_n_tasks = 0;   // last batch: workspace offsets of the tile tasks and their timing records
 };
@@ -401,6 +403,14 @@ int ka_engine_set_verify(ka_engine *e, int32_t flags)
     if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
     if (flags < 0 || flags > 7) return fail(KA_ERR_BAD_ARGS, "ka_engine_set_verify: flags are a combination of 1, 2 and 4");
     e->verify = flags;
+    return KA_OK;
+}
+
+int ka_engine_set_tile_waves(ka_engine *e, int32_t waves)
+{
+    if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
+    if (waves != 1 && waves != 2) return fail(KA_ERR_BAD_ARGS, "ka_engine_set_tile_waves: 1 or 2");
+    e->tile_waves = waves;
     return KA_OK;
 }
 
@@ -730,7 +740,16 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
             const bool contiguous = mem == KA_MEM_HOST || (ld[i] == V && ((uintptr_t)log_probs[i] & 15) == 0);
             if (!contiguous) pitch = 0;
         }
-#define KA_TP_LAUNCH(MM, PP, CC) hipLaunchKernelGGL((ka::forward_tp_kernel<MM, PP, CC>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket, verify, d_stats)
+        // two wavefronts per tile (ka_tiled2.hpp: one computes, one feeds) unless the engine was told otherwise
+#define KA_TP_LAUNCH(MM, PP, CC)                                                                                                                      \
+    do {                                                                                                                                              \
+        if (e->tile_waves == 2)                                                                                                                       \
+            hipLaunchKernelGGL((ka::forward_tp2_kernel<MM, PP, CC>), dim3(grid), dim3(128), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, \
+                               d_prog, d_aux, d_ticket, verify, d_stats);                                                                             \
+        else                                                                                                                                          \
+            hipLaunchKernelGGL((ka::forward_tp_kernel<MM, PP, CC>), dim3(grid), dim3(64), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo,  \
+                               d_prog, d_aux, d_ticket, verify, d_stats);                                                                             \
+    } while (0)
         if (pitch == 256 && V == 64) KA_TP_LAUNCH(4, 256, true);
         else if (pitch == 156) KA_TP_LAUNCH(4, 156, true);
         else switch (max_move) {
