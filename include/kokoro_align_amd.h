@@ -64,6 +64,11 @@ int ka_engine_reserve(ka_engine *e, size_t workspace_bytes);
 size_t ka_workspace_bytes(int32_t n, const int64_t *T, const int64_t *S, int32_t V,
                           int32_t beam_size, int32_t max_move);
 
+/* ... exactly what THIS engine (its mode, backtrace and device) will carve for such a call: the same planning code as the
+ * call itself, nothing is launched.  ka_workspace_bytes above is an upper bound over all modes. */
+size_t ka_engine_workspace_bytes(ka_engine *e, int32_t n, const int64_t *T, const int64_t *S, int32_t V, int32_t beam_size,
+                                 int32_t max_move, int32_t mem);
+
 /*
  * ctc_best_path(log_probs, labels, beam_size=1000, max_move=4) -> (best_path, best_labels, best_scores)
  * replaces kokoro_align/align.py:43-109 (DP align.py:62-93, backtrace :21-40,:99-102, gathers :105-107).
@@ -151,6 +156,10 @@ int ka_engine_set_backtrace(ka_engine *e, int32_t how);
 /* Per-kernel timing of the LAST enqueued batch, measured with HIP events recorded on the
  * launch stream: ms[0] label prep, ms[1] forward DP, ms[2] backtrace walk, ms[3] output
  * gathers (best_labels / best_scores).  Enable before the call; costs one event per kernel. */
+/* Calibration of KA_MODE_AUTO / KA_BACKTRACE_AUTO (tools/sweep_auto.py): with the lattices of a launch sorted longest
+ * first, run the longest n_tiled in the tiled form and walk the longest n_parallel back chunk-parallel instead of asking
+ * the cost model (ka_engine.hip); -1 = the cost model.  Results are identical whatever the split. */
+int ka_debug_set_split(ka_engine *e, int32_t n_tiled, int32_t n_parallel);
 /* Wavefronts per tile of the tiled form: 2 (default; ka_tiled2.hpp: one wavefront runs the frames, the other stages rows and
  * halo packets, polls, publishes) or 1 (ka_tiled.hpp: one wavefront does both).  Results are identical. */
 int ka_engine_set_tile_waves(ka_engine *e, int32_t waves);

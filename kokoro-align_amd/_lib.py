@@ -34,6 +34,7 @@ EXPORTS = [
     "ka_lstm_layer_f32", "ka_window_energy_f32", "ka_stft_frames_f32", "ka_power_f32", "ka_power_to_db_f32",
     "ka_debug_tile_stats", "ka_engine_set_backtrace", "ka_debug_chunk_entries", "ka_debug_plan_tiles",
     "ka_engine_set_verify", "ka_stream_create", "ka_stream_destroy", "ka_engine_set_tile_waves",
+    "ka_debug_set_split", "ka_engine_workspace_bytes",
 ]
 
 
@@ -81,6 +82,8 @@ def load_library():
     L.ka_engine_reserve.argtypes = [vp, sz]
     L.ka_workspace_bytes.restype = sz
     L.ka_workspace_bytes.argtypes = [i32, pi64, pi64, i32, i32, i32]
+    L.ka_engine_workspace_bytes.restype = sz
+    L.ka_engine_workspace_bytes.argtypes = [vp, i32, pi64, pi64, i32, i32, i32, i32]
     L.ka_ctc_best_path_f32.restype = ctypes.c_int
     L.ka_ctc_best_path_f32.argtypes = [vp, vp, i64, i32, i64, vp, i64, i32, i32, vp, vp, vp, vp, i32, vp]
     batch_common = [vp, i32, pp, pi64, i32, pi64, pp, pi64, i32, i32, pp, pp, pp]
@@ -98,6 +101,8 @@ def load_library():
     L.ka_stream_create.argtypes = [i32, pp]
     L.ka_stream_destroy.restype = ctypes.c_int
     L.ka_stream_destroy.argtypes = [i32, vp]
+    L.ka_debug_set_split.restype = ctypes.c_int
+    L.ka_debug_set_split.argtypes = [vp, i32, i32]
     L.ka_engine_set_tile_waves.restype = ctypes.c_int
     L.ka_engine_set_tile_waves.argtypes = [vp, i32]
     L.ka_engine_set_verify.restype = ctypes.c_int
@@ -196,6 +201,11 @@ class Engine:
         """'auto' | 'serial' (chunk after chunk) | 'parallel' (every chunk at once; ka_parallel_bt.hpp)"""
         code = {"auto": 0, "serial": 1, "parallel": 2}[how] if isinstance(how, str) else int(how)
         check(self.lib.ka_engine_set_backtrace(self.handle, code), "ka_engine_set_backtrace")
+
+    def set_split(self, n_tiled=-1, n_parallel=-1):
+        """Calibration of the AUTO modes: the longest n_tiled lattices of a launch run tiled, the longest n_parallel are walked
+        back chunk-parallel; -1 = the library's cost model."""
+        check(self.lib.ka_debug_set_split(self.handle, int(n_tiled), int(n_parallel)), "ka_debug_set_split")
 
     def set_tile_waves(self, waves):
         """Wavefronts per tile of the tiled form: 2 (default: one computes, one feeds) or 1."""

@@ -187,8 +187,10 @@ class DeviceBatch:
         self.total = np.zeros(self.n, np.float32)
 
     def workspace_bytes(self):
-        return int(self.engine.lib.ka_workspace_bytes(self.n, self._p_T, self._p_S, self.V, self.beam_size,
-                                                      self.max_move))
+        """device workspace this batch's engine will carve for it, with the engine's current mode settings"""
+        e = self.engine
+        return int(e.lib.ka_engine_workspace_bytes(e.handle, self.n, self._p_T, self._p_S, self.V, self.beam_size,
+                                                   self.max_move, _lib.KA_MEM_DEVICE))
 
     def enqueue(self):
         """Launch prep + forward DP + backtrace on torch's current stream; no host sync."""

@@ -189,6 +189,9 @@ struct ka_engine {
     int32_t last_V = 0, last_beam = 0, last_max_move = 0, last_mem = KA_MEM_DEVICE;
     int32_t verify = 0;                    // ka_engine_set_verify: self-checks of the tiled form's hand-off
     int32_t tile_waves = 2;                // ka_engine_set_tile_waves: wavefronts per tile of the tiled form
+    int32_t split_tiled = -1, split_par = -1;   // ka_debug_set_split: how many of the longest lattices run tiled / are walked back chunk-parallel (-1: cost model)
+    hipStream_t aux = nullptr;             // second stream: the other kernel form of a mixed launch runs beside the first
+    hipEvent_t sync[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t dbg_entry = 0, dbg_entry_n = 0, dbg_map0 = 0, dbg_map0_bytes = 0;   // last batch, descriptor 0: chunk entries and chunk maps
     size_t dbg_tasks = 0, dbg_stats = 0, dbg_n_tasks = 0;   // last batch: workspace offsets of the tile tasks and their timing records
 };
@@ -305,6 +308,13 @@ int ka_engine_create(int32_t device, ka_engine **out)
             return fail(KA_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(er));
         }
     }
+    for (int i = 0; i < 4; ++i) {
+        hipError_t er = hipEventCreateWithFlags(&e->sync[i], hipEventDisableTiming);
+        if (er != hipSuccess) {
+            ka_engine_destroy(e);
+            return fail(KA_ERR_HIP, std::string("hipEventCreateWithFlags: ") + hipGetErrorString(er));
+        }
+    }
     *out = e;
     return KA_OK;
 }
@@ -319,6 +329,9 @@ void ka_engine_destroy(ka_engine *e)
     if (e->pin) (void)hipHostFree(e->pin);
     for (int i = 0; i < 5; ++i)
         if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+    for (int i = 0; i < 4; ++i)
+        if (e->sync[i]) (void)hipEventDestroy(e->sync[i]);
+    if (e->aux) (void)hipStreamDestroy(e->aux);
     delete e;
 }
 
@@ -380,6 +393,23 @@ size_t ka_workspace_bytes(int32_t n, const int64_t *T, const int64_t *S, int32_t
     return total;
 }
 
+static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, const int64_t *T, int32_t V, const int64_t *ld,
+                        const int32_t *const *labels, const int64_t *S, int32_t beam_size, int32_t max_move, int32_t *const *best_path,
+                        int32_t *const *best_labels, float *const *best_scores, int32_t mem, hipStream_t stream, bool force_generic,
+                        size_t *plan_only_bytes);
+
+size_t ka_engine_workspace_bytes(ka_engine *e, int32_t n, const int64_t *T, const int64_t *S, int32_t V, int32_t beam_size, int32_t max_move,
+                                 int32_t mem)
+{
+    if (!e) return 0;
+    size_t bytes = 0;
+    const bool pending = e->pending;
+    e->pending = false;
+    const int rc = enqueue_impl(e, n, nullptr, T, V, nullptr, nullptr, S, beam_size, max_move, nullptr, nullptr, nullptr, mem, nullptr, false, &bytes);
+    e->pending = pending;
+    return rc == KA_OK ? bytes : 0;
+}
+
 int ka_engine_set_mode(ka_engine *e, int32_t mode)
 {
     if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
@@ -403,6 +433,14 @@ int ka_engine_set_verify(ka_engine *e, int32_t flags)
     if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
     if (flags < 0 || flags > 7) return fail(KA_ERR_BAD_ARGS, "ka_engine_set_verify: flags are a combination of 1, 2 and 4");
     e->verify = flags;
+    return KA_OK;
+}
+
+int ka_debug_set_split(ka_engine *e, int32_t n_tiled, int32_t n_parallel)
+{
+    if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
+    e->split_tiled = n_tiled < 0 ? -1 : n_tiled;
+    e->split_par = n_parallel < 0 ? -1 : n_parallel;
     return KA_OK;
 }
 
@@ -430,77 +468,184 @@ int ka_engine_last_kernel_ms(ka_engine *e, float ms[4])
     return KA_OK;
 }
 
-// The tiled form pays off when the one-wavefront-per-lattice form leaves the chip idle: a lattice costs ~5 concurrently
-// running tile wavefronts (a 1000-wide band touches 4-5 tiles), the chip has 1024 SIMDs.  Measured crossover: DESIGN.md.
-// (tools/sweep_auto.py, lattices of 20000 frames: tiled ahead up to 256 lattices - 3.55 vs 4.55 ms forward -, level at 384)
-constexpr int32_t kAutoTiledMaxLattices = 288;
-// The serial backtrace costs ~165 ns per frame of the LONGEST lattice (one wavefront each, side by side), the chunk-parallel
-// one ~0.62 ns per frame of ALL lattices (it is throughput-bound: it recomputes the whole band): parallel while
-// sum(T) < 256 max(T).  (same sweep: level at 256 lattices of equal length)
-constexpr int64_t kAutoParallelBacktraceFrameRatio = 256;
+// ---- KA_MODE_AUTO / KA_BACKTRACE_AUTO: which lattices of a launch run in which form --------------------------------------
+// A launch is a set of lattices of very different length (the chapters of a book or of a corpus span 20k .. 160k frames).
+// Each form has a CHAIN cost - the frames of a lattice are serial, so the longest lattice in a form bounds it - and a
+// THROUGHPUT cost - the chip's SIMDs are shared by everything in the launch.  Costs in microseconds per frame, measured on
+// MI355X (profiles/r03_sweep_auto_*.jsonl, tools/sweep_auto.py; cfg2-like stepping of the band):
+//   one wavefront per lattice, forward   chain 0.224 (11.2 ms / 50000 frames alone on its SIMD), vector-ALU time 0.097 per
+//                                        frame and SIMD (46 instructions x 4 cycles at 1.9 GHz: 45.8 ms for 8192 lattices)
+//   tiled, forward                       chain 0.085 (two wavefronts per tile: 4.0 ms for cfg2 + the lag of the tile chain),
+//                                        a tile holds one of the chip's 1024 workgroup slots for 0.12 per frame it lives
+//                                        (corpus: 462 chapters, all tiled, 12.0 ms), vector-ALU time 0.023 per tile and frame
+//   serial backtrace                     chain 0.173 (8.7 ms / 50000), throughput 0.0675 per frame and SIMD (27 ms for 8192)
+//   chunk-parallel backtrace             0.00066 per frame of every lattice in it (it recomputes the whole band) + 0.12 ms
+// The two forward kernels run side by side on two streams, and so do the two backtraces; with lattices sorted longest first
+// the longest k go tiled and the longest m are walked back chunk-parallel, k and m minimising
+//   forward(k)   = chain (+) throughput, chain = max(chain_tiled(T_0) x tmult, chain_wave(T_k) x wmult),
+//                  throughput = max(slots(k) x tmult, alu(k)),  a (+) b = max(a, b) + min(a, b) / 2
+//   backtrace(m) = max(chain_serial(T_m), parallel(m) + throughput_serial(m))
+// by a scan over the sorted lengths.  The two forms are not independent: they share the SIMDs.  A tile's wavefronts run at
+// the latency of their own instruction stream (55 % of it vector ALU), so w one-wavefront lattices on the same SIMD stretch
+// its frames by tmult = 1 + 0.55 w, and a resident tile stretches a one-wavefront lattice by wmult = 1 + 0.4 (sweep: 300
+// chapters of 80k-160k frames, the longest 225 tiled: 29 ms against 19 ms all tiled; 2000 chapters of 20k-100k: 28 ms with
+// one wavefront each, 43 ms with the longest 250 tiled).  Mixed launches pay when a few long lattices come with many short
+// ones (40 of 100k-160k + 1500 of 20k-40k: 41 ms one wavefront each, 31 ms all tiled, 21.5 ms with the longest ~100 tiled).
+// (Rounds 1-2 used a lattice count: <= 288 lattices tiled, sum(T) < 256 max(T) parallel, calibrated on equal lengths - 300
+// long chapters and 300 short ones got the same form.)
+struct AutoCosts {
+    double wave_chain = 0.224, wave_alu = 0.097;
+    double tile_chain = 0.095, tile_slot = 0.12, tile_alu = 0.023;
+    double tile_stretch = 0.55, wave_stretch = 0.40;
+    double serial_chain = 0.173, serial_thr = 0.0675;
+    double par_frame = 0.00066, par_fixed = 120.0;
+    double fork = 15.0;      // a second stream and its two event waits
+};
+constexpr AutoCosts kAuto;
+
+// lattices sorted longest first; alive[i] = tiles of lattice i that run at the same time.  Returns how many of the longest to tile.
+static int32_t auto_split_forward(const std::vector<int64_t> &T, const std::vector<int32_t> &alive, int32_t n_simd)
+{
+    const int32_t n = (int32_t)T.size();
+    if (n == 0) return 0;
+    const double simds = (double)n_simd;
+    std::vector<double> tile_slot(n + 1, 0.0), tile_alu(n + 1, 0.0), wave_alu(n + 1, 0.0), tiles(n + 1, 0.0);
+    for (int32_t i = 0; i < n; ++i) {
+        tile_slot[i + 1] = tile_slot[i] + (double)T[i] * alive[i] * kAuto.tile_slot / simds;
+        tile_alu[i + 1] = tile_alu[i] + (double)T[i] * alive[i] * kAuto.tile_alu / simds;
+        tiles[i + 1] = tiles[i] + alive[i];
+    }
+    for (int32_t i = n - 1; i >= 0; --i) wave_alu[i] = wave_alu[i + 1] + (double)T[i] * kAuto.wave_alu / simds;
+    std::vector<double> est(n + 1, 0.0);
+    for (int32_t k = 0; k <= n; ++k) {
+        const double tmult = 1.0 + kAuto.tile_stretch * (double)(n - k) / simds;
+        const double wmult = 1.0 + kAuto.wave_stretch * std::min(1.0, tiles[k] / simds);
+        double chain = 0.0;
+        if (k > 0) chain = kAuto.tile_chain * (double)T[0] * tmult;
+        if (k < n) chain = std::max(chain, kAuto.wave_chain * (double)T[k] * wmult);
+        const double thr = std::max(tile_slot[k] * tmult, tile_alu[k] + wave_alu[k]);
+        est[k] = std::max(chain, thr) + 0.5 * std::min(chain, thr);
+        if (k > 0 && k < n) est[k] += kAuto.fork;
+    }
+    const int32_t best_k = (int32_t)(std::min_element(est.begin(), est.end()) - est.begin());
+    // one kernel form is preferred when it is within 3 % of the best mix (the model is no better than that)
+    if (est[n] <= est[best_k] * 1.03) return n;
+    if (est[0] <= est[best_k] * 1.03) return 0;
+    return best_k;
+}
+// ... and how many of the longest to walk back chunk-parallel
+static int32_t auto_split_backtrace(const std::vector<int64_t> &T, int32_t n_simd)
+{
+    const int32_t n = (int32_t)T.size();
+    if (n == 0) return 0;
+    std::vector<double> par(n + 1, 0.0), ser(n + 1, 0.0);
+    for (int32_t i = 0; i < n; ++i) par[i + 1] = par[i] + (double)T[i] * kAuto.par_frame;
+    for (int32_t i = n - 1; i >= 0; --i) ser[i] = ser[i + 1] + (double)T[i] * kAuto.serial_thr / (double)n_simd;
+    double best = 0.0;
+    int32_t best_m = 0;
+    for (int32_t m = 0; m <= n; ++m) {
+        double est = (m > 0 ? kAuto.par_fixed + par[m] : 0.0) + ser[m];
+        if (m < n) est = std::max(est, kAuto.serial_chain * (double)T[m]);
+        if (m > 0 && m < n) est += kAuto.fork;
+        if (m == 0 || est < best * 0.97) {
+            best = est;
+            best_m = m;
+        }
+    }
+    return best_m;
+}
 
 static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, const int64_t *T, int32_t V,
                         const int64_t *ld, const int32_t *const *labels, const int64_t *S, int32_t beam_size,
                         int32_t max_move, int32_t *const *best_path, int32_t *const *best_labels,
-                        float *const *best_scores, int32_t mem, hipStream_t stream, bool force_generic = false)
+                        float *const *best_scores, int32_t mem, hipStream_t stream, bool force_generic, size_t *plan_only_bytes)
 {
     if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
     if (e->pending) return fail(KA_ERR_BAD_ARGS, "a batch is already enqueued: call ka_batch_finish first");
-    if (n < 0 || (n > 0 && (!log_probs || !T || !ld || !labels || !S || !best_path || !best_labels || !best_scores)))
+    const bool plan_only = plan_only_bytes != nullptr;     // ka_engine_workspace_bytes: sizes only, nothing is launched
+    if (n < 0 || (n > 0 && (!T || !S || (!plan_only && (!log_probs || !ld || !labels || !best_path || !best_labels || !best_scores)))))
         return fail(KA_ERR_BAD_ARGS, "batch: NULL array argument");
     if (mem != KA_MEM_HOST && mem != KA_MEM_DEVICE) return fail(KA_ERR_BAD_ARGS, "mem must be KA_MEM_HOST or KA_MEM_DEVICE");
     DeviceGuard guard;
-    KA_HIP(guard.enter(e->device));
-    e->n_last = n;
-    e->stream_last = stream;
-    e->have_times = false;
-    e->wide_tiled.clear();
-    e->redo.clear();
-    e->last_V = V;
-    e->last_beam = beam_size;
-    e->last_max_move = max_move;
-    e->last_mem = mem;
+    if (!plan_only) {
+        KA_HIP(guard.enter(e->device));
+        e->n_last = n;
+        e->stream_last = stream;
+        e->have_times = false;
+        e->wide_tiled.clear();
+        e->redo.clear();
+        e->last_V = V;
+        e->last_beam = beam_size;
+        e->last_max_move = max_move;
+        e->last_mem = mem;
+    }
     if (n == 0) {
-        e->pending = true;
+        if (plan_only) *plan_only_bytes = 0;
+        else e->pending = true;
         return KA_OK;
     }
 
     std::vector<Shape> sh(n);
-    int32_t n_fast_shaped = 0;
     for (int32_t i = 0; i < n; ++i) {
-        if (!shape_of(T[i], S[i], V, beam_size, max_move, sh[i]) || ld[i] < V)
+        if (!shape_of(T[i], S[i], V, beam_size, max_move, sh[i]) || (!plan_only && ld[i] < V))
             return fail(KA_ERR_BAD_ARGS, "lattice " + std::to_string(i) + ": unsupported T/S/V/ld/beam_size/max_move");
-        if (!log_probs[i] || !best_path[i] || !best_labels[i] || !best_scores[i] || (S[i] > 0 && !labels[i]))
+        if (!plan_only && (!log_probs[i] || !best_path[i] || !best_labels[i] || !best_scores[i] || (S[i] > 0 && !labels[i])))
             return fail(KA_ERR_BAD_ARGS, "lattice " + std::to_string(i) + ": NULL buffer");
-        n_fast_shaped += sh[i].fast ? 1 : 0;
     }
-    // ---- which lattices run in the tiled form (ka_tiled.hpp) ----
-    //   KA_MODE_TILED: every lattice that can;  KA_MODE_AUTO: bands too wide for the one-wavefront ring always, the
-    //   others when they are too few to fill the chip with one wavefront each
+    // ---- which lattices run in the tiled form (ka_tiled.hpp, ka_tiled2.hpp) ----
+    //   KA_MODE_TILED: every lattice that can;  KA_MODE_AUTO: bands too wide for the one-wavefront ring always, and of the
+    //   others the longest k, k from the cost model above (e->split_tiled >= 0: k given, for the calibration sweeps)
+    const bool checkpointed_waves = e->mode != KA_MODE_WORKGROUP && e->mode != KA_MODE_WAVE_EXACT;   // the one-wavefront lattices end in backtrace_rc
     int32_t n_tiled = 0;
-    {
-        const bool all = e->mode == KA_MODE_TILED;
-        const bool few = e->mode == KA_MODE_AUTO && n_fast_shaped <= kAutoTiledMaxLattices;
-        for (int32_t i = 0; i < n && !force_generic; ++i) {
-            if (!(all || (e->mode == KA_MODE_AUTO && (few || !sh[i].fast)))) continue;
+    if (!force_generic && (e->mode == KA_MODE_TILED || e->mode == KA_MODE_AUTO)) {
+        std::vector<int32_t> cand;      // fast-shaped lattices that could run tiled, longest first
+        for (int32_t i = 0; i < n; ++i) {
+            if (e->mode == KA_MODE_AUTO && sh[i].fast && sh[i].T >= (int64_t(1) << 26)) continue;   // (runs in the exact form)
             plan_tiles(sh[i], V, beam_size, max_move);
-            sh[i].tiled = sh[i].tileable;
-            n_tiled += sh[i].tiled ? 1 : 0;
+            if (!sh[i].tileable) continue;
+            if (e->mode == KA_MODE_TILED || !sh[i].fast) sh[i].tiled = true;
+            else cand.push_back(i);
         }
+        if (!cand.empty()) {
+            std::stable_sort(cand.begin(), cand.end(), [&](int32_t a, int32_t b) { return sh[a].T > sh[b].T; });
+            std::vector<int64_t> Ts(cand.size());
+            std::vector<int32_t> alive(cand.size());
+            for (size_t j = 0; j < cand.size(); ++j) {
+                const Shape &p = sh[cand[j]];
+                Ts[j] = p.T;
+                alive[j] = (int32_t)std::min<int64_t>((int64_t)p.t_in.size(), (p.W + 2 * ka::kTpTile - 1) / ka::kTpTile);
+            }
+            int32_t k = e->split_tiled >= 0 ? std::min<int32_t>(e->split_tiled, (int32_t)cand.size()) : auto_split_forward(Ts, alive, e->n_simd);
+            for (int32_t j = 0; j < k; ++j) sh[cand[j]].tiled = true;
+        }
+        for (int32_t i = 0; i < n; ++i) n_tiled += sh[i].tiled ? 1 : 0;
     }
 
-    // ---- chunk-parallel backtrace (ka_parallel_bt.hpp) for the checkpointed results when the lattices are too few to
-    // fill the chip with one backtrace wavefront each (it recomputes the whole band of every chunk, ~8x the serial
-    // form's work, but all chunks at once)
+    // ---- chunk-parallel backtrace (ka_parallel_bt.hpp) for the longest of the checkpointed results: it recomputes the
+    // whole band of every chunk, ~8x the serial form's work, but all chunks at once; the others are walked back serially,
+    // one wavefront each, at the same time on the engine's second stream
     {
-        int64_t sum_T = 0, max_T = 1;
-        for (int32_t i = 0; i < n; ++i) {
-            sum_T += sh[i].T;
-            max_T = std::max<int64_t>(max_T, sh[i].T);
-        }
-        const bool par = e->backtrace == KA_BACKTRACE_PARALLEL || (e->backtrace == KA_BACKTRACE_AUTO && sum_T < kAutoParallelBacktraceFrameRatio * max_T);
+        std::vector<int32_t> ring;      // lattices whose result backtrace_rc walks, longest first
         for (int32_t i = 0; i < n; ++i)
-            sh[i].par_bt = par && (sh[i].tiled || (sh[i].fast && e->mode != KA_MODE_WORKGROUP && e->mode != KA_MODE_WAVE_EXACT));
+            if (sh[i].tiled || (sh[i].fast && checkpointed_waves && sh[i].T < (int64_t(1) << 26))) ring.push_back(i);
+        std::stable_sort(ring.begin(), ring.end(), [&](int32_t a, int32_t b) { return sh[a].T > sh[b].T; });
+        int32_t m = 0;
+        if (e->backtrace == KA_BACKTRACE_PARALLEL) m = (int32_t)ring.size();
+        else if (e->backtrace == KA_BACKTRACE_AUTO) {
+            std::vector<int64_t> Ts(ring.size());
+            for (size_t j = 0; j < ring.size(); ++j) Ts[j] = sh[ring[j]].T;
+            m = e->split_par >= 0 ? std::min<int32_t>(e->split_par, (int32_t)ring.size()) : auto_split_backtrace(Ts, e->n_simd);
+        }
+        // grid limits of the chunk-parallel kernels
+        int64_t chunks = 0;
+        bool fits = (int64_t)n <= 65535;
+        for (int32_t j = 0; j < m && fits; ++j) {
+            const Shape &p = sh[ring[j]];
+            chunks += chunks_of_T(p.T);
+            fits = (p.W + 7 + ka::kCmOut - 1) / ka::kCmOut <= 65535 && supers_of_T(p.T) <= 65535 && chunks < (int64_t(1) << 31);
+        }
+        if (!fits) m = 0;
+        for (int32_t j = 0; j < m; ++j) sh[ring[j]].par_bt = true;
     }
 
     // ---- carve the workspace ----
@@ -566,6 +711,10 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
             off += align_up((size_t)sh[i].T * 4);
         }
     }
+    if (plan_only) {
+        *plan_only_bytes = off;
+        return KA_OK;
+    }
     int rc = ensure_ws(e, off);
     if (rc != KA_OK) return rc;
     rc = ensure_pin(e, align_up((size_t)n * sizeof(ka::Lattice)) + align_up((size_t)n * 16) + align_up(n_tasks * sizeof(ka::TileTask)));
@@ -589,8 +738,11 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
         const int32_t i = order[k];
         ka::Lattice &d = h_lats[k];
         std::memset(&d, 0, sizeof(d));
+        // chunks of the launch's chunk-parallel lattices are numbered consecutively; a lattice that is walked back serially
+        // carries the running total and owns none (lattice_of_chunk picks the LAST descriptor whose chunk0 <= chunk)
         d.chunk0 = chunk_cursor;
-        chunk_cursor += chunks_of_T(sh[i].T);
+        d.par = sh[i].par_bt ? 1 : 0;
+        if (sh[i].par_bt) chunk_cursor += chunks_of_T(sh[i].T);
         if (mem == KA_MEM_HOST) {
             d.lp = reinterpret_cast<const float *>(e->ws + cv[i].lp);
             d.labels = reinterpret_cast<const int32_t *>(e->ws + cv[i].lab);
@@ -710,6 +862,22 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
     if (e->profiling) KA_HIP(hipEventRecord(e->ev[0], stream));
     hipLaunchKernelGGL(ka::prep_labels_kernel, dim3(n), dim3(256), 0, stream, d_lats, d_meta);
     if (e->profiling) KA_HIP(hipEventRecord(e->ev[1], stream));
+    // A mixed launch runs its two kernel forms side by side: the second one on the engine's own stream, forked from the
+    // caller's stream behind the label preparation and joined to it again (events; nothing here blocks the host).
+    auto fork = [&](int k) -> hipError_t {
+        if (!e->aux) {
+            hipError_t er = hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking);
+            if (er != hipSuccess) return er;
+        }
+        hipError_t er = hipEventRecord(e->sync[k], stream);
+        return er != hipSuccess ? er : hipStreamWaitEvent(e->aux, e->sync[k], 0);
+    };
+    auto join = [&](int k) -> hipError_t {
+        hipError_t er = hipEventRecord(e->sync[k], e->aux);
+        return er != hipSuccess ? er : hipStreamWaitEvent(stream, e->sync[k], 0);
+    };
+    const bool two_forward = n_tiled > 0 && n_fast > 0;
+    if (two_forward) KA_HIP(fork(0));      // (before the tile kernel is enqueued: the second stream must not wait for it)
     Form form = kFormWaveExact;
     if (n_tiled > 0) {
         const unsigned grid = (unsigned)n_tasks, lds = ka::kTpLdsRequest;
@@ -762,21 +930,22 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
         form = kFormWaveCheckpointed;
     }
     if (n_fast > 0) {
-        // few lattices: 4 wavefronts per lattice (per-frame latency); many: 1 wavefront per lattice (throughput)
         const bool wg = e->mode == KA_MODE_WORKGROUP;
         form = wg ? kFormWorkgroup : (e->mode == KA_MODE_WAVE_EXACT ? kFormWaveExact : kFormWaveCheckpointed);
         // backtrace_rc_kernel keeps 34*T in 32 bits (descriptors are sorted longest first)
         if (form == kFormWaveCheckpointed && sh[order[n_tiled]].T >= (int64_t(1) << 26)) form = kFormWaveExact;
+        hipStream_t sw = two_forward ? e->aux : stream;
         switch (max_move) {
-        case 1: launch_forward<1>(d_lats + n_tiled, n_fast, d_meta, stream, form); break;
-        case 2: launch_forward<2>(d_lats + n_tiled, n_fast, d_meta, stream, form); break;
-        case 3: launch_forward<3>(d_lats + n_tiled, n_fast, d_meta, stream, form); break;
-        default: launch_forward<4>(d_lats + n_tiled, n_fast, d_meta, stream, form); break;
+        case 1: launch_forward<1>(d_lats + n_tiled, n_fast, d_meta, sw, form); break;
+        case 2: launch_forward<2>(d_lats + n_tiled, n_fast, d_meta, sw, form); break;
+        case 3: launch_forward<3>(d_lats + n_tiled, n_fast, d_meta, sw, form); break;
+        default: launch_forward<4>(d_lats + n_tiled, n_fast, d_meta, sw, form); break;
         }
     }
     if (n_tiled > 0) {
         // tiled lattices that the scores-only form declined (non-finite log-probs) and that fit the one-wavefront ring
-        // are redone by the exact kernels (kFlagExact; wider ones get kFlagDeclined and no result)
+        // are redone by the exact kernels (kFlagExact; wider ones get kFlagDeclined and are handed to the generic kernels
+        // by ka_batch_finish)
         switch (max_move) {
         case 1: launch_forward_flagged<1>(d_lats, n_tiled, d_meta, stream); break;
         case 2: launch_forward_flagged<2>(d_lats, n_tiled, d_meta, stream); break;
@@ -784,6 +953,7 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
         default: launch_forward_flagged<4>(d_lats, n_tiled, d_meta, stream); break;
         }
     }
+    if (two_forward) KA_HIP(join(1));
     if (n > n_ring)
         hipLaunchKernelGGL(ka::forward_generic_kernel, dim3(n - n_ring), dim3(256), 0, stream, d_lats + n_ring, d_meta);
     if (e->profiling) KA_HIP(hipEventRecord(e->ev[2], stream));
@@ -791,35 +961,40 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
     // the walk; [rc_lo, rc_hi) = descriptors whose outputs backtrace_rc writes itself
     const int32_t rc_lo = 0, rc_hi = n_tiled + (form == kFormWaveCheckpointed ? n_fast : 0);
     if (rc_hi > rc_lo) {
-        // chunk-parallel form: every descriptor of the range carries its maps (par_bt was decided per call)
+        // the chunk-parallel lattices of the range (Lattice::par; their chunks are numbered consecutively) and the others
         int64_t total_chunks = 0, max_seg = 1, max_sup = 1, max_w = 1;
-        bool par = true;
+        int32_t n_par = 0;
         for (int32_t k = rc_lo; k < rc_hi; ++k) {
             const Shape &p = sh[order[k]];
-            par = par && p.par_bt;
+            if (!p.par_bt) continue;
+            ++n_par;
             total_chunks += chunks_of_T(p.T);
             max_seg = std::max<int64_t>(max_seg, (p.W + 7 + ka::kCmOut - 1) / ka::kCmOut);
             max_sup = std::max<int64_t>(max_sup, supers_of_T(p.T));
             max_w = std::max<int64_t>(max_w, p.W);
         }
-        par = par && max_seg <= 65535 && max_sup <= 65535 && total_chunks < (int64_t(1) << 31) && rc_hi - rc_lo <= 65535;
-        if (par) {
+        const int nl = rc_hi - rc_lo;
+        const bool two_backtraces = n_par > 0 && n_par < nl;
+        if (n_par < nl) {      // one wavefront per lattice, chunk after chunk (skips the chunk-parallel ones)
+            if (two_backtraces) KA_HIP(fork(2));
+            hipStream_t ss = two_backtraces ? e->aux : stream;
+            switch (max_move) {
+            case 1: launch_backtrace_rc<1>(d_lats + rc_lo, nl, d_meta, ss); break;
+            case 2: launch_backtrace_rc<2>(d_lats + rc_lo, nl, d_meta, ss); break;
+            case 3: launch_backtrace_rc<3>(d_lats + rc_lo, nl, d_meta, ss); break;
+            default: launch_backtrace_rc<4>(d_lats + rc_lo, nl, d_meta, ss); break;
+            }
+        }
+        if (n_par > 0) {
             const unsigned gc = (unsigned)total_chunks, gs = (unsigned)max_seg;
-            const int nl = rc_hi - rc_lo;
             switch (max_move) {
             case 1: launch_parallel_bt<1>(d_lats + rc_lo, nl, d_meta, stream, gc, gs, (unsigned)max_sup, (unsigned)max_w); break;
             case 2: launch_parallel_bt<2>(d_lats + rc_lo, nl, d_meta, stream, gc, gs, (unsigned)max_sup, (unsigned)max_w); break;
             case 3: launch_parallel_bt<3>(d_lats + rc_lo, nl, d_meta, stream, gc, gs, (unsigned)max_sup, (unsigned)max_w); break;
             default: launch_parallel_bt<4>(d_lats + rc_lo, nl, d_meta, stream, gc, gs, (unsigned)max_sup, (unsigned)max_w); break;
             }
-        } else {
-            switch (max_move) {
-            case 1: launch_backtrace_rc<1>(d_lats + rc_lo, rc_hi - rc_lo, d_meta, stream); break;
-            case 2: launch_backtrace_rc<2>(d_lats + rc_lo, rc_hi - rc_lo, d_meta, stream); break;
-            case 3: launch_backtrace_rc<3>(d_lats + rc_lo, rc_hi - rc_lo, d_meta, stream); break;
-            default: launch_backtrace_rc<4>(d_lats + rc_lo, rc_hi - rc_lo, d_meta, stream); break;
-            }
         }
+        if (two_backtraces) KA_HIP(join(3));
         hipLaunchKernelGGL(ka::backtrace_w16_kernel, dim3(rc_hi - rc_lo), dim3(64), 0, stream, d_lats + rc_lo, d_meta, 1);
     }
     if (n_ring > rc_hi)
@@ -863,7 +1038,7 @@ int ka_ctc_best_path_batch_enqueue_f32(ka_engine *e, int32_t n, const float *con
                                        int32_t *const *best_labels, float *const *best_scores, void *stream)
 {
     return enqueue_impl(e, n, log_probs, T, V, ld, labels, S, beam_size, max_move, best_path, best_labels,
-                        best_scores, KA_MEM_DEVICE, (hipStream_t)stream);
+                        best_scores, KA_MEM_DEVICE, (hipStream_t)stream, false, nullptr);
 }
 
 int ka_batch_finish(ka_engine *e, float *total_score, int32_t *status)
@@ -904,7 +1079,7 @@ int ka_batch_finish(ka_engine *e, float *total_score, int32_t *status)
         e->profiling = false;      // the events keep the times of the batch itself
         const hipStream_t stream = e->stream_last;
         int rc = enqueue_impl(e, m, lp.data(), T.data(), e->last_V, ld.data(), lab.data(), S.data(), e->last_beam, e->last_max_move,
-                              path.data(), lab_out.data(), sc.data(), e->last_mem, stream, /*force_generic=*/true);
+                              path.data(), lab_out.data(), sc.data(), e->last_mem, stream, /*force_generic=*/true, nullptr);
         e->profiling = prof;
         e->pending = false;
         if (rc != KA_OK) return rc;
@@ -938,7 +1113,7 @@ int ka_ctc_best_path_batch_f32(ka_engine *e, int32_t n, const float *const *log_
                                void *stream)
 {
     int rc = enqueue_impl(e, n, log_probs, T, V, ld, labels, S, beam_size, max_move, best_path, best_labels,
-                          best_scores, mem, (hipStream_t)stream);
+                          best_scores, mem, (hipStream_t)stream, false, nullptr);
     if (rc != KA_OK) return rc;
     return ka_batch_finish(e, total_score, status);
 }

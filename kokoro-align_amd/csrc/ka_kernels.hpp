@@ -94,7 +94,9 @@ struct Lattice {
     uint8_t *map0;          // [chunk c][ck_pitch / 4]: how far the best path into position p of frame 32c+31 has risen since frame 32c-1
     uint16_t *map1;         // [super-chunk s][ck_pitch / 4]: the same over the 32 chunks of a super-chunk
     int32_t *entry;         // [chunks]: best-path position at the last frame of every chunk, then [super-chunks]: of every super-chunk
-    int64_t chunk0;         // index of this lattice's chunk 0 among the chunks of the launch
+    int64_t chunk0;         // index of this lattice's chunk 0 among the chunks of the launch's chunk-parallel lattices
+    int32_t par;            // 1: walked back by the chunk-parallel kernels, 0: by one wavefront (backtrace_rc_kernel<.., false>)
+    int32_t pad_;
 };
 
 // meta[4*idx + {0,1,2,3}] = status, end position, flags (bit0: a transcript label is 0), total score bits
@@ -1507,7 +1509,7 @@ __device__ __forceinline__ uint64_t lane_field(uint32_t count, uint32_t first)
 //     (v_add_f32_dpp .. wave_ror:1) instead of through a v_mov_dpp each;
 //   * the blank cell's candidates from the lane below are rotations of ONE sum: score(pb-1) + e0 = ror(sl + e0) and
 //     score(pb-3) + e0 = ror of that again - e0 is the same in every lane, so this is the same float add on the same
-//     operands, carried out in another lane.  (DPP takes no scalar operand.  KA_RC_E0_SCALAR = 0 fetches e0 into a VGPR
+//     operands, carried out in another lane.  (DPP takes no scalar operand.  Fetching e0 into a VGPR
 //     with a second ds_bpermute instead, so that all three lane-below operands go through DPP adds: two vector
 //     instructions fewer, and slower - the LDS pipe is shared by the CU's four SIMDs);
 //   * the label emission is gathered one frame ahead and waited for at the end of the block;
@@ -1518,26 +1520,14 @@ __device__ __forceinline__ uint64_t lane_field(uint32_t count, uint32_t first)
 // and first add between them and the next DPP read; inside the block every DPP source is written at least three
 // instructions earlier (an s_nop fills in where the veto is compiled out).
 // `word` takes 4 code bits per frame exactly as cell_blank<4> / cell_label<4> would shift them in.
-#ifndef KA_RC_DIAG
-#define KA_RC_DIAG 0
-#endif
-#ifndef KA_RC_WALK_GATHERS
-#define KA_RC_WALK_GATHERS 1
-#endif
-#ifndef KA_RC_E0_SCALAR
-#define KA_RC_E0_SCALAR 1
-#endif
-#if KA_RC_E0_SCALAR
+// (The timing experiments of DESIGN.md 4.7 - builds of this block without its loads, gathers, codes or walk, results wrong by
+//  design - were preprocessor variants of this code up to round 2, commit d171691; they are not part of the shipped source.)
 // the blank emission as a scalar (v_readfirstlane): one LDS-pipe instruction less per frame - that pipe is shared by
 // the CU's four SIMDs and a ds_bpermute holds it for 7 cycles (tools/ubench/lds_rates.hip) - for one more DPP move:
 // DPP takes no scalar operand, so score(pb-1) + e0 is formed as ror(sl + e0).
 #define KA_RC_E0_OUT "=&s"
 #define KA_RC_E0_IN "s"
-#if KA_RC_DIAG == 2   // (timing experiment, results wrong: no emission gathers)
-#define KA_RC_GATHER "v_mov_b32 %[eln], %[rown]\n\tv_readfirstlane_b32 %[e0n], %[rown]\n\t"
-#else
 #define KA_RC_GATHER "ds_bpermute_b32 %[eln], %[lab4], %[rown]\n\tv_readfirstlane_b32 %[e0n], %[rown]\n\t"
-#endif
 #define KA_RC_HEAD                                                                        \
     KA_RC_GATHER                                                                          \
     "v_add_f32 %[t2], %[e0], %[sl]\n\t"                                                   \
@@ -1555,46 +1545,12 @@ __device__ __forceinline__ uint64_t lane_field(uint32_t count, uint32_t first)
     "s_nop 0\n\t"                                                                         \
     "v_mov_b32_dpp %[t2], %[t1] wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"                \
     "v_max3_f32 %[sb], %[t0], %[t1], %[t2]\n\t"
-#else
-#define KA_RC_E0_OUT "=&v"
-#define KA_RC_E0_IN "v"
-#if KA_RC_DIAG == 2   // (timing experiment, results wrong: no emission gathers)
-#define KA_RC_GATHER "v_mov_b32 %[eln], %[rown]\n\tv_mov_b32 %[e0n], %[rown]\n\t"
-#else
-#define KA_RC_GATHER "ds_bpermute_b32 %[eln], %[lab4], %[rown]\n\tds_bpermute_b32 %[e0n], %[zero], %[rown]\n\t"
-#endif
-#define KA_RC_HEAD                                                                        \
-    KA_RC_GATHER                                                                          \
-    "v_add_f32_dpp %[t1], %[sl], %[e0] wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"         \
-    "v_add_f32_dpp %[t4], %[sl], %[el] wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"         \
-    "v_add_f32_dpp %[t5], %[sb], %[el] wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"         \
-    "v_add_f32 %[t0], %[sb], %[e0]\n\t"                                                   \
-    "v_add_f32 %[t3], %[sb], %[el]\n\t"                                                   \
-    "v_add_f32 %[t7], %[sl], %[el]\n\t"
-#define KA_RC_VETO "v_min_f32 %[t4], %[t4], %[veto]\n\t"
-#define KA_RC_MAX                                                                         \
-    "v_mov_b32_dpp %[t2], %[t1] wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"                \
-    "v_max_f32 %[t6], %[t7], %[t3]\n\t"                                                   \
-    "v_max3_f32 %[sl], %[t6], %[t4], %[t5]\n\t"                                           \
-    "v_max3_f32 %[sb], %[t0], %[t1], %[t2]\n\t"
-#endif
-#if KA_RC_DIAG == 3   // (timing experiment, results wrong: no back-pointer codes)
-#define KA_RC_CODES_X ""
-#else
-#define KA_RC_CODES_X KA_RC_CODES
-#endif
-#if KA_RC_DIAG == 7   // (timing experiment, results wrong: the label cell's compare masks are not combined)
-#define KA_RC_COMBINE                                                                     \
-    "v_addc_co_u32 %[w], %[sy], %[w], %[w], %[sb2]\n\t"                                   \
-    "v_addc_co_u32 %[w], %[sx], %[w], %[w], %[sc]\n\t"
-#else
 #define KA_RC_COMBINE                                                                     \
     "s_or_b64 %[sx], %[sa], %[sb2]\n\t"                                                   \
     "v_addc_co_u32 %[w], %[sy], %[w], %[w], %[sx]\n\t"                                    \
     "s_andn2_b64 %[sc], %[sc], %[sb2]\n\t"                                                \
     "s_or_b64 %[sc], %[sc], %[sa]\n\t"                                                    \
     "v_addc_co_u32 %[w], %[sy], %[w], %[w], %[sc]\n\t"
-#endif
 #define KA_RC_CODES                                                                       \
     "v_cmp_eq_f32 %[sa], %[t0], %[sb]\n\t"                                                \
     "v_addc_co_u32 %[w], %[sy], %[w], %[w], %[sa]\n\t"                                    \
@@ -1606,15 +1562,7 @@ __device__ __forceinline__ uint64_t lane_field(uint32_t count, uint32_t first)
     KA_RC_COMBINE
 // band select, skipped by a scalar branch inside the block when the chunk is open (a branch around two asm blocks made
 // hipcc allocate the loop-carried registers differently on the two sides and reconcile them with three v_mov per frame)
-#if KA_RC_DIAG == 9   // (timing experiment: eight idle instructions, 32 bytes, per frame)
-#define KA_RC_PAD "s_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\t"
-#elif KA_RC_DIAG == 10   // (timing experiment: four idle vector instructions of 8 bytes per frame)
-#define KA_RC_PAD "v_max3_f32 %[t6], %[t6], %[t6], %[t6]\n\tv_max3_f32 %[t5], %[t5], %[t5], %[t5]\n\tv_max3_f32 %[t6], %[t6], %[t6], %[t6]\n\tv_max3_f32 %[t5], %[t5], %[t5], %[t5]\n\t"
-#else
-#define KA_RC_PAD ""
-#endif
 #define KA_RC_BAND                                                                        \
-    KA_RC_PAD                                                                             \
     "s_bitcmp1_b32 %[open], 0\n\t"                                                        \
     "s_cbranch_scc1 .Lka_rc_open_%=\n\t"                                                  \
     "v_cndmask_b32 %[sb], %[ninf], %[sb], %[mb]\n\t"                                      \
@@ -1636,21 +1584,19 @@ __device__ __forceinline__ void rc_frame4(float &sb, float &sl, uint32_t &word, 
     float t0, t1, t2, t3, t4, t5, t6, t7;
     uint64_t sa, sb2, sc, sx, sy;
     if constexpr (ZL)
-        asm volatile(KA_RC_HEAD KA_RC_VETO KA_RC_MAX KA_RC_CODES_X KA_RC_BAND : KA_RC_OUTS : KA_RC_INS, [veto] "v"(veto) : "memory", "scc");
+        asm volatile(KA_RC_HEAD KA_RC_VETO KA_RC_MAX KA_RC_CODES KA_RC_BAND : KA_RC_OUTS : KA_RC_INS, [veto] "v"(veto) : "memory", "scc");
     else
-        asm volatile(KA_RC_HEAD KA_RC_MAX KA_RC_CODES_X KA_RC_BAND : KA_RC_OUTS : KA_RC_INS : "memory", "scc");
+        asm volatile(KA_RC_HEAD KA_RC_MAX KA_RC_CODES KA_RC_BAND : KA_RC_OUTS : KA_RC_INS : "memory", "scc");
 }
 #undef KA_RC_HEAD
 #undef KA_RC_GATHER
 #undef KA_RC_E0_OUT
 #undef KA_RC_E0_IN
-#undef KA_RC_CODES_X
 #undef KA_RC_VETO
 #undef KA_RC_MAX
 #undef KA_RC_CODES
 #undef KA_RC_COMBINE
 #undef KA_RC_BAND
-#undef KA_RC_PAD
 #undef KA_RC_OUTS
 #undef KA_RC_INS
 constexpr int kRcLanes = 62;   // lanes 62 and 63 are kept at -inf: they are the "nothing below position 0" that
@@ -1720,6 +1666,7 @@ __global__ __launch_bounds__(64, KA_RC_MIN_WAVES) void backtrace_rc_kernel(const
     const int which = PAR ? __builtin_amdgcn_readfirstlane(lattice_of_chunk(lats, n_lats, (int64_t)blockIdx.x)) : (int)blockIdx.x;
     const Lattice &d = lats[which];
     const int lane = threadIdx.x;
+    if (!PAR && __builtin_amdgcn_readfirstlane(d.par)) return;   // the chunk-parallel kernels walk this one (a mixed launch runs both)
     const int32_t *mt = meta + 4 * (size_t)d.idx;
     const int flags = __builtin_amdgcn_readfirstlane(mt[2]);
     if (flags & (kFlagExact | kFlagDeclined)) return;        // handled by the exact kernels / not at all
@@ -1777,11 +1724,7 @@ __global__ __launch_bounds__(64, KA_RC_MIN_WAVES) void backtrace_rc_kernel(const
             if (n == kCkFrames) {
 #pragma unroll
                 for (int f = 0; f < kCkFrames; ++f) {
-#if KA_RC_DIAG == 1   // (timing experiment, results wrong: no log-prob rows from memory)
-                    rows[f] = -1.0f - (float)f;
-#else
                     rows[f] = row_load(col_off, rp);
-#endif
                     rp += ldb;
                 }
             } else {
@@ -1861,17 +1804,10 @@ __global__ __launch_bounds__(64, KA_RC_MIN_WAVES) void backtrace_rc_kernel(const
             const int zero = 0;
             float e0c, elc, e0n, eln;
             row_wait_n(rows[0], kCkFrames - 1);
-#if KA_RC_E0_SCALAR
             asm volatile("ds_bpermute_b32 %0, %2, %4\n\t"
                          "v_readfirstlane_b32 %1, %4\n\t"
                          "s_waitcnt lgkmcnt(0)"
                          : "=&v"(elc), "=&s"(e0c) : "v"(lab4), "v"(zero), "v"(rows[0]) : "memory");
-#else
-            asm volatile("ds_bpermute_b32 %0, %2, %4\n\t"
-                         "ds_bpermute_b32 %1, %3, %4\n\t"
-                         "s_waitcnt lgkmcnt(0)"
-                         : "=&v"(elc), "=&v"(e0c) : "v"(lab4), "v"(zero), "v"(rows[0]) : "memory");
-#endif
             // the frames after which floor(L*t/T) moves, as a bit mask: the common frame then pays one s_bitcmp1 +
             // s_cbranch for the band instead of a scalar Bresenham step
             uint32_t moves = 0;
@@ -1916,16 +1852,11 @@ __global__ __launch_bounds__(64, KA_RC_MIN_WAVES) void backtrace_rc_kernel(const
                 sl = select_by_mask(NINF, ml, mask_l);
             }
         }
-#if KA_RC_DIAG == 4   // (timing experiment, results wrong: no walk, no outputs)
-        int qq = p - wlo - (p > 3000 ? 6 : 0);
-        if (lane == 70) path[t0] = (int)codes[0] + (int)codes[3];
-#else
         // ---- walk back over the chunk: pathv[lane f] = position of frame t0+f, relative to wlo ----
 #pragma unroll
         for (int g = 0; g < kCkFrames / 8; ++g) codes[g] = rc_blank_to_uniform(codes[g]);
         int pathv = 0;
         int qq = p - wlo;
-#if KA_RC_WALK_GATHERS
         // best_path, best_labels = lab'[best_path], best_scores[t] = lp[t, best_labels[t]] (align.py:105-107), lane f
         // does frame t0+f: collected by the walk itself (rc_walk_out)
         int labv = 0;
@@ -1939,41 +1870,6 @@ __global__ __launch_bounds__(64, KA_RC_MIN_WAVES) void backtrace_rc_kernel(const
             lab_out[t0 + lane] = labv;
             sc_out[t0 + lane] = scv;
         }
-#else
-#if KA_RC_DIAG == 5   // (timing experiment, results wrong: no walk)
-        pathv = (qq - (31 - lane) / 6) & 127;
-        qq -= p > 3000 ? 6 : 0;
-        if (lane == 70) path[t0] = (int)codes[0] + (int)codes[3];
-#else
-        if (n == kCkFrames)
-            rc_walk<true>(codes, n, qq, pathv);
-        else
-            rc_walk<false>(codes, n, qq, pathv);
-#endif
-        // best_path, best_labels = lab'[best_path], best_scores[t] = lp[t, best_labels[t]] (align.py:105-107):
-        // lane f does frame t0+f.  The score comes from the row registers (lane v of rows[f] = lp[t0+f, v]): a
-        // gather from memory would fetch a 128-byte line per frame again (measured: +57 GB per batch, and
-        // this kernel runs at HBM speed).  Frame f: every lane looks up its own column in row f, lane f keeps it.
-        {
-            const int pos = pathv + wlo;
-            // 4 * label = byte address of the column: the window's labels are in registers (lane j: position wlo+2j+1)
-            const int lw = __builtin_amdgcn_ds_bpermute((pathv >> 1) * 4, lab4);
-            const int l4 = (lane < n && (pos & 1)) ? lw : 0;
-            float sv = 0.0f;
-#if KA_RC_DIAG != 6   // (6: timing experiment, results wrong: no score gather)
-#pragma unroll
-            for (int f = 0; f < kCkFrames; ++f) {
-                sv = select_by_mask(sv, bperm(l4, rows[f]), 1ull << f);   // lane f keeps its column of row f
-            }
-#endif
-            if (lane < n) {
-                path[t0 + lane] = pos;
-                lab_out[t0 + lane] = l4 >> 2;
-                sc_out[t0 + lane] = sv;
-            }
-        }
-#endif
-#endif
         p = qq + wlo;
         if (PAR || t0 == 0) break;
         t0 -= kCkFrames;

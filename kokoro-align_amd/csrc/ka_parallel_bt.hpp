@@ -285,6 +285,7 @@ __global__ __launch_bounds__(64) void chunk_map_kernel(const Lattice *__restrict
 __global__ __launch_bounds__(256) void compose_maps_kernel(const Lattice *__restrict__ lats, const int32_t *meta)
 {
     const Lattice &d = lats[blockIdx.z];
+    if (!d.par) return;
     const int32_t *mt = meta + 4 * (size_t)d.idx;
     if ((mt[2] & (kFlagExact | kFlagDeclined)) || mt[0] != kStatusOk || mt[1] < 0) return;
     const int T = d.T, nck = chunks_of(T), nsup = supers_of(nck);
@@ -309,6 +310,7 @@ __global__ __launch_bounds__(256) void compose_maps_kernel(const Lattice *__rest
 __global__ __launch_bounds__(256) void chain_entries_kernel(const Lattice *__restrict__ lats, const int32_t *meta)
 {
     const Lattice &d = lats[blockIdx.x];
+    if (!d.par) return;
     const int32_t *mt = meta + 4 * (size_t)d.idx;
     if ((mt[2] & (kFlagExact | kFlagDeclined)) || mt[0] != kStatusOk || mt[1] < 0) return;
     const int T = d.T, nck = chunks_of(T), nsup = supers_of(nck);

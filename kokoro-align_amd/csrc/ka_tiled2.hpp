@@ -10,12 +10,11 @@
 //   iteration `it` (both wavefronts, after the barrier):
 //     compute:  frames of block it (LDS rows / packets of blocks it and it+1 - the reads run two frames ahead), drops its
 //               per-frame packets into staging buffer it & 1, stores the checkpoint if the block ends on one
-//     feeder:   publishes block it-1's packets (staging buffer (it-1) & 1), polls the tile below for block it+3 and requests
-//               it (LDS ring slot of block it-1: free since the barrier), waits until only those requests are in flight
-//               (block it+2 has landed, the packets are out), announces block it-1 in the progress word and sums block
-//               it+2 for the finiteness check
-//   so the compute wavefront finds blocks it+1 and it+2 landed at barrier it+1, and the feeder has a whole iteration of the
-//   compute wavefront (~1.8 us) between a request and the wait for it.
+//     feeder:   polls the tile below for block it+2 and requests it, publishes block it-1's packets (staging buffer
+//               (it-1) & 1), sums block it+1 for the finiteness check, works out block it+1's band bookkeeping, then waits
+//               for EVERYTHING it has in flight (s_waitcnt vmcnt(0)) and announces block it-1 in the progress word
+//   so the compute wavefront finds blocks it+1 and it+2 landed at barrier it+1, the requests have the whole iteration of the
+//   compute wavefront (~1.8 us) to land, and a block is announced one iteration after it was computed.
 // Everything of the hand-off protocol (sc1 packets, in-order vmcnt accounting, progress words, bounded stall detector) is
 // the feeder's alone, exactly as in the one-wavefront form; the compute wavefront's only vector-memory instruction is the
 // checkpoint store.  Same LDS request (40 KB: 4 workgroups per CU), twice the wavefronts.
@@ -155,7 +154,6 @@ __device__ __forceinline__ void tp2_run_tile(const Lattice &d, const TileTask &t
         }
         if (lane == 0) __builtin_amdgcn_global_load_lds((gptr_t)c.prog_in, (lptr_t)(lchar_t)(uintptr_t)(lds_poll + slot * 4), 4, 0, 16);
     };
-    constexpr int kIssued = kRowDmas + 2;   // vector-memory instructions of one issue_block
     bool stale = false;
     auto landed_block = [&](int32_t k) {
         const uint32_t slot = ring(k);
@@ -185,44 +183,30 @@ __device__ __forceinline__ void tp2_run_tile(const Lattice &d, const TileTask &t
     bool fed = true;
     TpIn cur = {f32x2{0.0f, 0.0f}, 0.0f, f32x4{NINF, NINF, NINF, NINF}}, nxt = cur;
     float H[3] = {NINF, NINF, NINF};
-    // Iterations kb0-3 .. kb0-1 prime the feeder's pipeline; iteration kb1+1 publishes the last block.
-    for (int32_t it = kb0 - 3; it <= kb1 + 1; ++it) {
+    // Iterations kb0-2, kb0-1 prime the feeder's pipeline; iteration kb1+1 publishes the last block.
+    for (int32_t it = kb0 - 2; it <= kb1 + 1; ++it) {
         const uint32_t tb = (uint32_t)(it * kTpBlock);              // (wraps in the priming iterations of block 0: not used there)
         tp2_barrier();
         if (feeder) {
             phase(-1);
-            // block it-1 is complete in staging buffer (it-1) & 1: lane f < 32 stores the packet of frame f as slot tb-32+f+1.
-            // FIRST thing of the iteration, and in front of this iteration's requests in program order: the counted wait below
-            // then vouches for these stores too, and the progress word can announce block it-1 in the iteration after it
-            // was computed (two iterations earlier than with the stores behind the requests: every block of lag between a
-            // tile and the one below it is paid once per tile of the chain)
+            // block it+2 is requested now (LDS ring slot of block it-2): the tile below must have published its packets (the
+            // freshest look at its progress word that has landed came with block it+1)
+            if (it + 2 <= kb1 && fed) {
+                const uint32_t have = it + 1 >= kb0 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_bit_cast(uint32_t, lds_f32(lds_poll + ring(it + 1) * 4))) : 0u;
+                fed = tp_wait_progress(c.prog_in, need_for(it + 2), need_for(it + 4), have, stat_lds);
+            }
+            phase(5);
+            if (it + 2 >= 0 && it + 2 <= kb1 + 1) issue_block(it + 2);
+            phase(6);
+            // block it-1 is complete in staging buffer (it-1) & 1: lane f < 32 stores the packet of frame f as slot tb-32+f+1
             const bool published = it - 1 >= kb0 && it - 1 <= kb1;
             if (published) {
                 c.lds_packets = lds_stage0 + (uint32_t)((it - 1) & 1) * kTpStageBytes;
                 tp_publish_block(c, tb - kTpBlock, lane);
             }
             phase(7);
-            // block it+3 is requested now: the tile below must have published its packets (the freshest look at its
-            // progress word that has landed came with block it+1)
-            if (it + 3 <= kb1 && fed) {
-                const uint32_t have = it + 1 >= kb0 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_bit_cast(uint32_t, lds_f32(lds_poll + ring(it + 1) * 4))) : 0u;
-                fed = tp_wait_progress(c.prog_in, need_for(it + 3), need_for(it + 5), have, stat_lds);
-            }
-            phase(5);
-            // block it+2 (requested an iteration ago) must be in LDS before the compute wavefront reaches it; only this
-            // iteration's requests may still be in flight
-            if (it + 3 >= 0 && it + 3 <= kb1 + 1) {
-                issue_block(it + 3);
-                phase(6);
-                if (verify & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" : : "i"(kIssued) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            phase(3);
-            // retired by that wait: everything older than this iteration's requests - the packets of block it-1 = slots <= tb
-            if (published) tp_prog_store(c.prog_out, tb + 1);
-            if (it + 2 >= kb0 && it + 2 <= kb1) landed_block(it + 2);
+            // block it+1 landed before the last barrier: its finiteness sum
+            if (it + 1 >= kb0 && it + 1 <= kb1) landed_block(it + 1);
             // the band bookkeeping of the NEXT block (which positions of the tile enter or leave the band in which frame), for
             // the compute wavefront to pick up after the next barrier: ~60 instructions it does not have to issue
             if (it + 1 >= kb0 && it + 1 <= kb1) {
@@ -234,6 +218,17 @@ __device__ __forceinline__ void tp2_run_tile(const Lattice &d, const TileTask &t
                 tp_band_advance(c);
             }
             phase(4);
+            // EVERYTHING this wavefront has in flight is waited for, once per iteration: the requests of block it+2 (the compute
+            // wavefront reads its first rows in the next iteration) and the packets just published.  No counted wait: a
+            // counted vmcnt orders loads among loads and stores among stores, not one against the other - announcing block
+            // it-1 behind "at most the requests are outstanding" would rest on stores retiring before younger loads, which
+            // is not something the ISA promises.  The requests have had the whole iteration to land, and the feeder is idle
+            // for half of it anyway.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            phase(3);
+            // slots <= tb are in memory - but never vouch for more than the tile's own frames have produced: the slots behind
+            // t_end are filled (with -inf) after the loop, and the final progress word covers those
+            if (published) tp_prog_store(c.prog_out, (tb < (uint32_t)c.t_end ? tb : (uint32_t)c.t_end) + 1);
         } else if (it >= kb0 && it <= kb1) {
             const uint32_t slot = ring(it), nslot = ring(it + 1);
             uint32_t rc = c.lds_rows + slot * kTpSlotBytes, rn = c.lds_rows + nslot * kTpSlotBytes;

@@ -312,3 +312,62 @@ def test_meian_book_with_the_hand_off_self_check_on(books_on_device):
     finally:
         eng.set_verify(0)
         _set(eng, "auto")
+
+
+def test_corpus_under_auto_sample_vs_oracle_and_properties_on_all():
+    """The unit of work of the reference's run_example.py without --dataset: the 14 enabled datasets of example.json as ONE
+    launch (462 chapter lattices, 20k..94k frames) under KA_MODE_AUTO / KA_BACKTRACE_AUTO - the regime in which the library
+    has to pick a kernel form per lattice (the longest tiled, the others one wavefront each; the longest walked back
+    chunk-parallel, the others serially).  40 chapters spread over the length range against the C oracle, bit for bit; every
+    chapter through size-independent properties.  The same with the split forced to a few other places: results must not
+    depend on it."""
+    import torch
+    from kokoro_align_amd import workloads as W
+    from kokoro_align_amd.align import DeviceBatch
+    shapes, seeds = [], []
+    for k, (_, sh) in enumerate(W.corpus()):
+        shapes += sh
+        seeds += [W.corpus_seed0(k) + i for i in range(len(sh))]
+    lps, labs = [], []
+    for (T, S), seed in zip(shapes, seeds):
+        lp1, lab1 = W.device_book([(T, S)], seed0=seed)
+        lps += lp1; labs += lab1
+    n = len(shapes)
+    by_len = sorted(range(n), key=lambda i: shapes[i][0])
+    sample = [by_len[j] for j in np.linspace(0, n - 1, 40).astype(int)]
+    from concurrent.futures import ThreadPoolExecutor
+
+    def oracle_one(i):
+        T, S = shapes[i]
+        return O.ctc_best_path_c(O.hash_logprobs_c(T, W.V_MODEL, seeds[i]), O.hash_labels(S, W.V_MODEL, seeds[i]), 1000, 4, return_total=True)
+    O.lib()
+    with ThreadPoolExecutor(max_workers=max(1, min(16, (os.cpu_count() or 2) - 1))) as ex:
+        want = dict(zip(sample, ex.map(oracle_one, sample)))
+    eng = _engine()
+    _set(eng, "auto")
+    try:
+        first = None
+        # (all 462 tiled = ~2300 tiles for 1024 workgroup slots: tiles start late, next to producers that are about to finish;
+        #  repeated, because what can go wrong there - a progress word that vouches for more than is in memory - is a race)
+        for split in ((-1, -1), (n // 3, n // 5), (7, n - 3), (0, n), (n, 0), (n, 0), (n, 0), (n, n // 2)):
+            eng.set_split(*split)
+            b = DeviceBatch(lps, labs)
+            st = b.run(raise_on_error=False)
+            assert not (st != 0).any(), split
+            for i in sample:
+                _compare(b, i, want[i], f"split {split}, chapter {i} (T = {shapes[i][0]})")
+            if first is None:
+                first = [p.clone() for p in b.path]
+                for i in range(n):      # properties on every chapter
+                    T, S = shapes[i]
+                    p = b.path[i]
+                    d = p[1:] - p[:-1]
+                    assert int(d.min()) >= 0 and int(d.max()) <= 3 and int(p[-1]) == 2 * S, i
+                chain_ok = [np.add.accumulate(b.best_scores[i].cpu().numpy(), dtype=np.float32)[-1].view(np.int32) == np.float32(b.total[i]).view(np.int32)
+                            for i in range(0, n, 5)]
+                assert all(chain_ok)
+            else:
+                assert all(torch.equal(a, c) for a, c in zip(first, b.path)), split
+    finally:
+        eng.set_split(-1, -1)
+        _set(eng, "auto")
