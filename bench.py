@@ -288,6 +288,76 @@ def corpus_entry():
     return out
 
 
+def pipeline_entry():
+    """SURVEY.md section 8f end to end on the Kokoro stand-in (64 chapters, 2.77 M frames = 8.78 h of audio): MFCC rows on the
+    host -> AudioToChar on the device (kokoro_align_amd.model.lstm_logits_device: library GEMMs + the persistent MFMA
+    recurrence kernel) -> ONE log-softmax launch -> the chapters' DP as one launch.  Random-init network of the reference's
+    architecture (train.py:54-65), random MFCC-shaped input cut into segments of 200..1200 frames as the reference's
+    splitter produces them; stage times from HIP events, second pass (allocator and library heuristics warm)."""
+    import numpy as np
+    import torch
+    import kokoro_align_amd as ka
+    from kokoro_align_amd import workloads as W
+    from kokoro_align_amd.align import DeviceBatch
+    from kokoro_align_amd.model import load_model, lstm_logits_device
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rng = np.random.default_rng(0)
+    torch.manual_seed(0)
+    model = load_model(None, device=dev)
+    V = model.dense.out_features
+    name, shapes = W.kokoro_book()
+    ends, row = [], 0
+    for T, _ in shapes:
+        left = T
+        while left > 0:
+            n = int(min(left, rng.integers(200, 1200)))
+            row += n
+            left -= n
+            ends.append(row)
+    total = row
+    mfcc = rng.standard_normal((total, 40), dtype=np.float32)
+    labels = [torch.from_numpy(rng.integers(1, V, size=S).astype(np.int32)).to(dev) for _, S in shapes]
+    out = {}
+    for rep in range(2):
+        tm = {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        logits = lstm_logits_device(model, mfcc, np.asarray(ends), device=dev, timings=tm)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        lp = ka.log_softmax_device(logits)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        lps, k = [], 0
+        for T, _ in shapes:
+            lps.append(lp[k:k + T])
+            k += T
+        b = DeviceBatch(lps, labels)
+        b.engine.set_profiling(True)
+        b.run()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        km = b.engine.last_kernel_ms()
+        b.engine.set_profiling(False)
+        ok = all(int(p[-1]) == 2 * S for p, (_, S) in zip(b.path, shapes))
+        net = sum(tm.values())
+        out = {"workload": name + ", 64 chapters as %d MFCC segments" % len(ends), "frames": total,
+               "network_ms": (t1 - t0) * 1e3, "network_stages_ms": {k_: round(v, 3) for k_, v in tm.items()}, "network_stages_sum_ms": net,
+               "log_softmax_ms": (t2 - t1) * 1e3, "ctc_best_path_ms": (t3 - t2) * 1e3,
+               "ctc_kernels_ms": {"forward": km["forward"], "backtrace": km["backtrace"]},
+               "end_to_end_ms": (t3 - t0) * 1e3, "frames_per_s_end_to_end": total / (t3 - t0),
+               "all_paths_end_at_the_trailing_blank": bool(ok)}
+        del b, lps, lp, logits
+    # the recurrence kernel against the f32 MFMA peak (MI355X_MICROARCH.md: 157.3 TFLOP/s)
+    rec = sum(v for k_, v in out["network_stages_ms"].items() if k_.startswith("recurrence"))
+    flops = 2.0 * total * 2 * 2 * 128 * 512      # 2 flop per MAC x frames x directions x layers x (128 x 512)
+    out["recurrence"] = {"ms_both_layers": rec, "tflops": flops / (rec * 1e-3) / 1e12, "f32_mfma_peak_tflops": 157.3,
+                         "frac_of_peak": flops / (rec * 1e-3) / 1e12 / 157.3,
+                         "note": "chain-bound: the longest segment (1199 steps) x 5.4 us per step; 16 sequences per workgroup"}
+    torch.cuda.empty_cache()
+    return out
+
+
 def np_bits(x):
     import numpy as np
     return int(np.float32(x).view(np.int32))
@@ -563,6 +633,7 @@ def main():
             torch.cuda.empty_cache()
             out.update(latency_entries(lps0, labs0))
             out["corpus"] = corpus_entry()
+            out["pipeline"] = pipeline_entry()
         if cpu is not None:
             attach_cpu_baseline(out, cpu, args.workload)
         sys.stdout.flush()

@@ -60,7 +60,8 @@ int ka_stream_create(int32_t device, void **stream);
 int ka_stream_destroy(int32_t device, void *stream);
 /* pre-size the workspace so that later calls do not allocate (optional) */
 int ka_engine_reserve(ka_engine *e, size_t workspace_bytes);
-/* device-workspace bytes one batch call needs (back-pointers dominate: 256 B per frame) */
+/* device-workspace bytes one batch call needs at most, whatever the engine's mode (every lattice priced in its most
+ * expensive form: tiled with chunk-parallel backtrace); ka_engine_workspace_bytes gives the exact figure for an engine */
 size_t ka_workspace_bytes(int32_t n, const int64_t *T, const int64_t *S, int32_t V,
                           int32_t beam_size, int32_t max_move);
 

@@ -389,7 +389,7 @@ size_t ka_workspace_bytes(int32_t n, const int64_t *T, const int64_t *S, int32_t
     }
     if (tasks)
         total += align_up(align_up((1 + tasks) * 4 + (size_t)n * sizeof(ka::TileAux) + 16, 16)) + align_up(tasks * sizeof(ka::TileTask)) +
-                 align_up((size_t)(ninf_slots + 2 * ka::kTpBlock) * 16);
+                 align_up(tasks * sizeof(ka::TpStats)) + align_up((size_t)(ninf_slots + 2 * ka::kTpBlock) * 16);
     return total;
 }
 

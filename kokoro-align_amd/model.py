@@ -52,7 +52,7 @@ def segment_logits(model, segments, device=None, batch_size=128):
 
 
 @torch.no_grad()
-def lstm_logits_device(model, data, indices, device=None, persistent=True):
+def lstm_logits_device(model, data, indices, device=None, persistent=True, timings=None):
     """Logits of every frame of an IndexDataArray (``data`` [rows, n_mfcc], ``indices`` = cumulative segment ends,
     kokoro_align/preprocess.py:12-35), [rows, vocab] on ``device`` in the file's row order - what the reference's
     predict() writes to *.logits.npz (train.py:215-231) - computed for ALL segments at once.
@@ -64,7 +64,8 @@ def lstm_logits_device(model, data, indices, device=None, persistent=True):
         workgroup carries 32 sequences through all their steps, h @ W_hh^T on the f32 MFMA with W_hh resident in
         registers), or per time step one batched library GEMM + the fused cell kernel ka_lstm_step_f32,
     with the segments sorted by length.  Inference only (no dropout); float32; equal to the PyTorch network
-    within rounding (tests: 1e-4).
+    within rounding (tests: 1e-4).  ``timings`` (a dict): filled with the milliseconds of every stage (HIP events on the
+    current stream; one synchronisation at the end).
     """
     import numpy as np
     from . import _lib
@@ -75,7 +76,16 @@ def lstm_logits_device(model, data, indices, device=None, persistent=True):
     ends = np.asarray(indices, dtype=np.int64).reshape(-1)
     n = int(ends.size)
     total = int(ends[-1]) if n else 0
+    marks = []
+
+    def mark(name):
+        if timings is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(device))
+            marks.append((name, ev))
+    mark("start")
     x_file = torch.as_tensor(data, dtype=torch.float32)[:total].to(device)
+    mark("h2d_mfcc")
     if total == 0:
         return torch.zeros((0, model.dense.out_features), dtype=torch.float32, device=device)
     starts = np.concatenate([[0], ends[:-1]])
@@ -117,12 +127,14 @@ def lstm_logits_device(model, data, indices, device=None, persistent=True):
         bias = torch.cat([sd["lstm.bias_ih" + s] + sd["lstm.bias_hh" + s] for s in sfx], 0)  # [8H]
         w_hh_t = torch.stack([sd["lstm.weight_hh" + s].t().contiguous() for s in sfx], 0)  # [2, H, 4H]
         gin = torch.addmm(bias, inp, w_ih.t())                                             # [total, 8H]
+        mark(f"input_projection_l{layer}")
         out = torch.empty((total, 2 * H), dtype=torch.float32, device=device)
         if persistent:
             # the whole layer in one launch: ka_lstm_layer_f32 (f32 MFMA, W_hh register-resident, h in LDS)
             w_hh = torch.stack([sd["lstm.weight_hh" + s] for s in sfx], 0).contiguous()      # [2, 4H, H]
             _lib.check(lib.ka_lstm_layer_f32(gin.data_ptr(), gin.stride(0), w_hh.data_ptr(), out.data_ptr(), out.stride(0),
                                              d_offs32.data_ptr(), d_len32.data_ptr(), n, H, stream), "ka_lstm_layer_f32")
+            mark(f"recurrence_l{layer}")
             del gin
             inp = out
             continue
@@ -139,9 +151,15 @@ def lstm_logits_device(model, data, indices, device=None, persistent=True):
             rc = step(*args, rows_ptr + t * rows_step, rows_dir, n_run[t], H, stream)
             if rc:
                 _lib.check(rc, "ka_lstm_step_f32")
+        mark(f"recurrence_l{layer}")
         del gin
         inp = out
     logits_sorted = torch.addmm(sd["dense.bias"], inp, sd["dense.weight"].t())
+    mark("dense")
+    if timings is not None:
+        torch.cuda.synchronize(device)
+        for (_, a), (name, b) in zip(marks[:-1], marks[1:]):
+            timings[name] = timings.get(name, 0.0) + a.elapsed_time(b)
     if perm is None:
         return logits_sorted
     logits = torch.empty_like(logits_sorted)

@@ -86,11 +86,12 @@ def _write_logits(indices, logits, output_file, text_file):
         raise
 
 
-def predict_files(model, audio_files, output_files, text_files, device=None):
+def predict_files(model, audio_files, output_files, text_files, device=None, log_probs_out=None):
     """predict() for many files at once: the MFCC segments of ALL files go through the network together
     (kokoro_align_amd.model.lstm_logits_device: a time step of the LSTM costs the same for 60 sequences or
     4000), then every file's outputs are written in the reference's formats.  Returns {output_file: logits
-    [T_file, vocab] on the device}."""
+    [T_file, vocab] on the device}.  ``log_probs_out`` (a dict): also filled with {output_file: log-probs of align.py:116-117},
+    computed for the whole dataset by ONE launch of the HIP log-softmax kernel (the files' rows are one tensor here)."""
     import torch
     from .model import lstm_logits_device
     device = device or next(model.parameters()).device
@@ -105,11 +106,14 @@ def predict_files(model, audio_files, output_files, text_files, device=None):
     if not audio_files:
         return {}
     logits = lstm_logits_device(model, torch.from_numpy(np.concatenate(datas, axis=0)), np.concatenate(ends), device=device)
+    log_probs = log_softmax_device(logits) if log_probs_out is not None else None
     result = {}
     for (indices, b, rows), of, tf in zip(per_file, output_files, text_files):
         lg = logits[b:b + rows]
         _write_logits(indices, lg, of, tf)
         result[of] = lg
+        if log_probs is not None:
+            log_probs_out[of] = log_probs[b:b + rows]
     return result
 
 
@@ -136,13 +140,14 @@ def predict(model, audio_file, output_file, text_file, device=None, batch_size=1
 # stage: best_path for many files in one launch
 # ------------------------------------------------------------------------------------------
 def best_path_files(logits_files, voca_files, best_path_files_out, device=None, logits_on_device=None,
-                    host_softmax=False):
+                    host_softmax=False, log_probs_on_device=None):
     """All files of a dataset as ONE batched launch (the reference loops them, run_example.py:248-254).
 
     ``logits_on_device`` (optional) maps a logits file name to a device tensor produced by
     ``predict`` in this process; files not in the map are read from disk.  ``host_softmax``
     computes align.py:116-117 with NumPy on the host (bit-identical log-probs to the
-    reference); the default runs the HIP log-softmax kernel on the device (1e-6).
+    reference); the default runs the HIP log-softmax kernel on the device (1e-6) - once per file, or not at all for the
+    files whose log-probs ``log_probs_on_device`` already holds (predict_files computes them for a whole dataset in one launch).
     Files whose output exists are skipped.  Returns the list of files written.
     """
     import torch
@@ -154,6 +159,10 @@ def best_path_files(logits_files, voca_files, best_path_files_out, device=None, 
         return []
     lps, labs = [], []
     for lf, vf, _ in todo:
+        if not host_softmax and log_probs_on_device is not None and lf in log_probs_on_device:
+            lps.append(log_probs_on_device[lf])
+            labs.append(read_transcript(vf))
+            continue
         if logits_on_device is not None and lf in logits_on_device:
             logits = logits_on_device[lf]
         else:
@@ -284,18 +293,34 @@ def process_alignment_sharded(dataset, audio_files, metadata_file, model=None, r
         rank, world_size = dist.get_rank(), dist.get_world_size()
         if barrier is None:
             barrier = dist.barrier
-    shapes = []
-    for af in audio_files:
-        mf, vf = _swap_ext([af], '.mp3', '.mfcc.npz')[0], _swap_ext([af], '.mp3', '.voca.txt')[0]
-        with np.load(mf) as f:
-            ends = f['indices']
-        shapes.append((int(ends[-1]) if len(ends) else 0, int(len(read_transcript(vf)))))
-    mine = [audio_files[i] for i in shard_for_rank(shapes, rank, world_size)]
-    if mine:
-        process_alignment(dataset, mine, None, model=model, remove_wordsep=remove_wordsep, device=device,
-                          host_softmax=host_softmax, verbose=verbose, best_path_files_fn=best_path_files_fn)
+    # The split_audio stage first, files dealt round-robin (its outputs size the shards below): a dataset whose MFCCs have not
+    # been made yet goes through the same stage process_alignment would run, instead of failing on a missing file.
+    failure = None
+    try:
+        for af in audio_files[rank::world_size]:
+            _ensure_mfcc(af, print if verbose else (lambda *a, **k: None))
+    except BaseException as exc:       # every rank must reach the barrier: a rank that raised before it would hang the others
+        failure = exc
     if barrier is not None:
         barrier()
+    if failure is None:
+        try:
+            shapes = []
+            for af in audio_files:
+                mf, vf = _swap_ext([af], '.mp3', '.mfcc.npz')[0], _swap_ext([af], '.mp3', '.voca.txt')[0]
+                with np.load(mf) as f:
+                    ends = f['indices']
+                shapes.append((int(ends[-1]) if len(ends) else 0, int(len(read_transcript(vf)))))
+            mine = [audio_files[i] for i in shard_for_rank(shapes, rank, world_size)]
+            if mine:
+                process_alignment(dataset, mine, None, model=model, remove_wordsep=remove_wordsep, device=device,
+                                  host_softmax=host_softmax, verbose=verbose, best_path_files_fn=best_path_files_fn)
+        except BaseException as exc:
+            failure = exc
+    if barrier is not None:
+        barrier()
+    if failure is not None:
+        raise failure
     if rank != 0:
         return None
     say = print if verbose else (lambda *a, **k: None)
@@ -308,6 +333,21 @@ def process_alignment_sharded(dataset, audio_files, metadata_file, model=None, r
     return metadata_file
 
 
+def _ensure_mfcc(af, say):
+    """The split_audio stage of one file (run_example.py:205-218): `<x>.split.txt` + `<x>.mfcc.npz` from the decoded audio
+    `<x>.wav` / `<x>.npy`, skipped when both exist."""
+    sf, mf = _swap_ext([af], '.mp3', '.split.txt')[0], _swap_ext([af], '.mp3', '.mfcc.npz')[0]
+    if os.path.exists(sf) and os.path.exists(mf):
+        say(f'Skip converting {af} to MFCC')
+        return
+    decoded = [f for f in _swap_ext([af], ".mp3", ".wav") + _swap_ext([af], ".mp3", ".npy") if os.path.exists(f)]
+    if not decoded:
+        raise FileNotFoundError(f'{sf} / {mf} are missing and there is no decoded audio ({af[:-4]}.wav or .npy) to make them from')
+    say(f'Converting {decoded[0]} to MFCC')
+    from .preprocess import split_audio
+    split_audio(decoded[0], sf, mf)
+
+
 def process_alignment(dataset, audio_files, metadata_file, model=None, remove_wordsep=False, device=None,
                       host_softmax=False, verbose=True, best_path_files_fn=None):
     """Given `<x>.mp3` names whose `<x>.voca.txt` exist (made by the reference's upstream stages), run
@@ -318,22 +358,14 @@ def process_alignment(dataset, audio_files, metadata_file, model=None, remove_wo
     say = print if verbose else (lambda *a, **k: None)
     mfcc = _swap_ext(audio_files, '.mp3', '.mfcc.npz')
     split = _swap_ext(audio_files, '.mp3', '.split.txt')
-    for af, sf, mf in zip(audio_files, split, mfcc):
-        if os.path.exists(sf) and os.path.exists(mf):
-            say(f'Skip converting {af} to MFCC')
-            continue
-        decoded = [f for f in _swap_ext([af], ".mp3", ".wav") + _swap_ext([af], ".mp3", ".npy") if os.path.exists(f)]
-        if not decoded:
-            raise FileNotFoundError(f'{sf} / {mf} are missing and there is no decoded audio ({af[:-4]}.wav or .npy) to make them from')
-        say(f'Converting {decoded[0]} to MFCC')
-        from .preprocess import split_audio
-        split_audio(decoded[0], sf, mf)
+    for af in audio_files:
+        _ensure_mfcc(af, say)
     voca = _swap_ext(audio_files, '.mp3', '.voca.txt')
     logits = _swap_ext(audio_files, '.mp3', '.logits.npz')
     greed = _swap_ext(audio_files, '.mp3', '.greed.txt')
     bpath = _swap_ext(audio_files, '.mp3', '.best_path.npz')
     align_out = _swap_ext(audio_files, '.mp3', '.align.txt')
-    on_device = {}
+    on_device, lp_on_device = {}, {}
     missing = []
     for mf, lf, gf in zip(mfcc, logits, greed):
         if os.path.exists(lf) and os.path.exists(gf):   # both outputs, like run_example.py:227
@@ -347,12 +379,14 @@ def process_alignment(dataset, audio_files, metadata_file, model=None, remove_wo
         import torch
         dev = torch.device(device) if device is not None else next(model.parameters()).device
         if dev.type == "cuda":     # every missing file through the network in one go
-            on_device = predict_files(model, [m[0] for m in missing], [m[1] for m in missing], [m[2] for m in missing], device=dev)
+            on_device = predict_files(model, [m[0] for m in missing], [m[1] for m in missing], [m[2] for m in missing], device=dev,
+                                      log_probs_out=None if host_softmax else lp_on_device)
         else:
             for mf, lf, gf in missing:
                 on_device[lf] = predict(model, mf, lf, gf, device=dev)
+    extra = {} if best_path_files_fn is not None else {"log_probs_on_device": lp_on_device}
     written = (best_path_files_fn or best_path_files)(logits, voca, bpath, device=device, logits_on_device=on_device,
-                                                       host_softmax=host_softmax)
+                                                       host_softmax=host_softmax, **extra)
     for bf in bpath:
         say(f'Writing {bf}' if bf in written else f'Skip writing {bf}')
     for bf, mf, vf, af in zip(bpath, mfcc, voca, align_out):
