@@ -161,6 +161,9 @@ int ka_engine_set_backtrace(ka_engine *e, int32_t how);
  * first, run the longest n_tiled in the tiled form and walk the longest n_parallel back chunk-parallel instead of asking
  * the cost model (ka_engine.hip); -1 = the cost model.  Results are identical whatever the split. */
 int ka_debug_set_split(ka_engine *e, int32_t n_tiled, int32_t n_parallel);
+/* LDS bytes a tile workgroup of the tiled form requests (0 = the library's choice; 40 KB lets four workgroups share a CU, 80 KB
+ * two): an occupancy experiment knob, results are identical. */
+int ka_debug_set_tile_lds(ka_engine *e, int32_t bytes);
 /* Wavefronts per tile of the tiled form: 2 (default; ka_tiled2.hpp: one wavefront runs the frames, the other stages rows and
  * halo packets, polls, publishes) or 1 (ka_tiled.hpp: one wavefront does both).  Results are identical. */
 int ka_engine_set_tile_waves(ka_engine *e, int32_t waves);

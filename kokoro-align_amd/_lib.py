@@ -34,7 +34,7 @@ EXPORTS = [
     "ka_lstm_layer_f32", "ka_window_energy_f32", "ka_stft_frames_f32", "ka_power_f32", "ka_power_to_db_f32",
     "ka_debug_tile_stats", "ka_engine_set_backtrace", "ka_debug_chunk_entries", "ka_debug_plan_tiles",
     "ka_engine_set_verify", "ka_stream_create", "ka_stream_destroy", "ka_engine_set_tile_waves",
-    "ka_debug_set_split", "ka_engine_workspace_bytes",
+    "ka_debug_set_split", "ka_engine_workspace_bytes", "ka_debug_set_tile_lds",
 ]
 
 
@@ -101,6 +101,8 @@ def load_library():
     L.ka_stream_create.argtypes = [i32, pp]
     L.ka_stream_destroy.restype = ctypes.c_int
     L.ka_stream_destroy.argtypes = [i32, vp]
+    L.ka_debug_set_tile_lds.restype = ctypes.c_int
+    L.ka_debug_set_tile_lds.argtypes = [vp, i32]
     L.ka_debug_set_split.restype = ctypes.c_int
     L.ka_debug_set_split.argtypes = [vp, i32, i32]
     L.ka_engine_set_tile_waves.restype = ctypes.c_int
@@ -206,6 +208,9 @@ class Engine:
         """Calibration of the AUTO modes: the longest n_tiled lattices of a launch run tiled, the longest n_parallel are walked
         back chunk-parallel; -1 = the library's cost model."""
         check(self.lib.ka_debug_set_split(self.handle, int(n_tiled), int(n_parallel)), "ka_debug_set_split")
+
+    def set_tile_lds(self, nbytes):
+        check(self.lib.ka_debug_set_tile_lds(self.handle, int(nbytes)), "ka_debug_set_tile_lds")
 
     def set_tile_waves(self, waves):
         """Wavefronts per tile of the tiled form: 2 (default: one computes, one feeds) or 1."""

@@ -189,6 +189,7 @@ struct ka_engine {
     int32_t last_V = 0, last_beam = 0, last_max_move = 0, last_mem = KA_MEM_DEVICE;
     int32_t verify = 0;                    // ka_engine_set_verify: self-checks of the tiled form's hand-off
     int32_t tile_waves = 2;                // ka_engine_set_tile_waves: wavefronts per tile of the tiled form
+    int32_t tile_lds = 0;                  // ka_debug_set_split's third knob: LDS bytes a tile workgroup requests (0: kTpLdsRequest)
     int32_t split_tiled = -1, split_par = -1;   // ka_debug_set_split: how many of the longest lattices run tiled / are walked back chunk-parallel (-1: cost model)
     hipStream_t aux = nullptr;             // second stream: the other kernel form of a mixed launch runs beside the first
     hipEvent_t sync[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -433,6 +434,14 @@ int ka_engine_set_verify(ka_engine *e, int32_t flags)
     if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
     if (flags < 0 || flags > 7) return fail(KA_ERR_BAD_ARGS, "ka_engine_set_verify: flags are a combination of 1, 2 and 4");
     e->verify = flags;
+    return KA_OK;
+}
+
+int ka_debug_set_tile_lds(ka_engine *e, int32_t bytes)
+{
+    if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
+    if (bytes != 0 && (bytes < (int32_t)ka::kTpLdsRequest || bytes > 160 * 1024)) return fail(KA_ERR_BAD_ARGS, "ka_debug_set_tile_lds: 0 or 40 KB .. 160 KB");
+    e->tile_lds = bytes;
     return KA_OK;
 }
 
@@ -880,7 +889,12 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
     if (two_forward) KA_HIP(fork(0));      // (before the tile kernel is enqueued: the second stream must not wait for it)
     Form form = kFormWaveExact;
     if (n_tiled > 0) {
-        const unsigned grid = (unsigned)n_tasks, lds = ka::kTpLdsRequest;
+        // 40 KB of LDS per tile workgroup = four workgroups per CU; when the launch has no more tiles than two per CU, 80 KB
+        // keeps them at two per CU, i.e. (two wavefronts each) one wavefront per SIMD: two tiles whose wavefronts share a SIMD
+        // run at 95-106 ns per frame instead of 55-62, and a chain runs at the pace of its slowest tile (cfg5's whole lattice,
+        // 391 tiles alive for all 500 000 frames: profiles/r03_tile_stats_cfg5_full.txt)
+        const unsigned grid = (unsigned)n_tasks;
+        const unsigned lds = e->tile_lds ? (unsigned)e->tile_lds : ((int64_t)n_tasks <= (int64_t)e->n_simd / 2 && e->tile_waves == 2 ? 2u * ka::kTpLdsRequest : ka::kTpLdsRequest);
         // ka_engine_set_verify(1) (tests): every halo slot starts as a NaN pattern and a tile that consumes one reports KA_ERR_INTERNAL
         const int verify = e->verify;
         if (verify & 1) {
@@ -1174,6 +1188,7 @@ int ka_debug_tile_stats(ka_engine *e, uint64_t *out, int32_t max_tasks)
         uint64_t *o = out + 8 * i;
         o[0] = (uint64_t)tk[i].lat; o[1] = (uint64_t)tk[i].tile; o[2] = (uint64_t)tk[i].t_in; o[3] = (uint64_t)tk[i].t_end;
         o[4] = st[i].wait_ticks; o[5] = st[i].total_ticks; o[6] = st[i].spins; o[7] = st[i].start_tick;
+        o[2] |= (st[i].phase[2] >> 32) << 32;      // (two-wavefront tiles: HW_ID of the compute wavefront in the high half of t_in)
         if ((e->verify & 4) && (i == 0 || i == 10 || i == 20)) std::fprintf(stderr, "[ka_debug_tile_stats] ticket %zu cycles per phase: wait %llu, check+sum %llu, progress %llu, requests %llu, publish %llu\n", i,
                                  (unsigned long long)(uint32_t)st[i].phase[0], (unsigned long long)(st[i].phase[0] >> 32), (unsigned long long)(uint32_t)st[i].phase[1],
                                  (unsigned long long)(st[i].phase[1] >> 32), (unsigned long long)st[i].phase[2]);

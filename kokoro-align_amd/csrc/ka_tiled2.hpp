@@ -54,6 +54,11 @@ __device__ __forceinline__ void tp2_run_tile(const Lattice &d, const TileTask &t
             ph = now;
         }
     };
+    if ((verify & 4) && !feeder && lane == 0) {   // where the compute wavefront runs (the feeder reports its own place below)
+        uint32_t hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        ((lu32_t)(uintptr_t)stat_lds)[10] = hw & 0xffffu;
+    }
     if ((verify & 4) && feeder) {   // start stamps: wall clock (100 MHz) and shader clock
         stats_out->start_tick = (unsigned long long)wall_clock64();
         stats_out->total_ticks = __builtin_amdgcn_s_memtime();
@@ -193,7 +198,9 @@ __device__ __forceinline__ void tp2_run_tile(const Lattice &d, const TileTask &t
             // freshest look at its progress word that has landed came with block it+1)
             if (it + 2 <= kb1 && fed) {
                 const uint32_t have = it + 1 >= kb0 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_bit_cast(uint32_t, lds_f32(lds_poll + ring(it + 1) * 4))) : 0u;
-                fed = tp_wait_progress(c.prog_in, need_for(it + 2), need_for(it + 4), have, stat_lds);
+                // (no hysteresis here: the one-wavefront tile asks for two blocks more than it needs once it has to wait, so that
+                //  its frames are not interrupted by a poll per block; here the frames run in the other wavefront)
+                fed = tp_wait_progress(c.prog_in, need_for(it + 2), need_for(it + 2), have, stat_lds);
             }
             phase(5);
             if (it + 2 >= 0 && it + 2 <= kb1 + 1) issue_block(it + 2);
@@ -306,7 +313,7 @@ __device__ __forceinline__ void tp2_run_tile(const Lattice &d, const TileTask &t
             st.spins = sw[0] | ((unsigned long long)((xcc & 0xf) << 16 | (hw & 0xffff))) << 32;
             st.phase[0] = sw[3] | ((unsigned long long)sw[4] << 32);
             st.phase[1] = sw[5] | ((unsigned long long)sw[6] << 32);
-            st.phase[2] = sw[7];
+            st.phase[2] = sw[7] | ((unsigned long long)sw[10] << 32);   // (high half: HW_ID of the compute wavefront)
             st.wait_ticks = sw[1] | ((unsigned long long)sw[2] << 32);
             st.start_tick = __builtin_amdgcn_s_memtime() - stats_out->total_ticks;
             st.total_ticks = wall_clock64() - stats_out->start_tick;
