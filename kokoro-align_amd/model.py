@@ -52,7 +52,7 @@ def segment_logits(model, segments, device=None, batch_size=128):
 
 
 @torch.no_grad()
-def lstm_logits_device(model, data, indices, device=None, persistent=True, timings=None, chunked_upload_min_rows=1 << 18):
+def lstm_logits_device(model, data, indices, device=None, persistent=True, timings=None):
     """Logits of every frame of an IndexDataArray (``data`` [rows, n_mfcc], ``indices`` = cumulative segment ends,
     kokoro_align/preprocess.py:12-35), [rows, vocab] on ``device`` in the file's row order - what the reference's
     predict() writes to *.logits.npz (train.py:215-231) - computed for ALL segments at once.
@@ -65,8 +65,7 @@ def lstm_logits_device(model, data, indices, device=None, persistent=True, timin
         registers), or per time step one batched library GEMM + the fused cell kernel ka_lstm_step_f32,
     with the segments sorted by length.  Inference only (no dropout); float32; equal to the PyTorch network
     within rounding (tests: 1e-4).  ``timings`` (a dict): filled with the milliseconds of every stage (HIP events on the
-    current stream; one synchronisation at the end).  Host input of at least ``chunked_upload_min_rows`` rows is uploaded
-    in 8 row chunks on a second stream, each projected (layer 0) while the next is on its way.
+    current stream; one synchronisation at the end).
     """
     import numpy as np
     from . import _lib
@@ -85,34 +84,8 @@ def lstm_logits_device(model, data, indices, device=None, persistent=True, timin
             ev.record(torch.cuda.current_stream(device))
             marks.append((name, ev))
     mark("start")
-    host = torch.as_tensor(data, dtype=torch.float32)[:total]
-    # The MFCC rows come from the host (443 MB for an 8.8-hour book: 8 ms of PCIe) and the first thing done with them is the
-    # layer-0 input projection, row by row independent: upload in row chunks on a second stream and project chunk c while
-    # chunk c+1 is on its way (persistent path; `gin0` is then ready when the upload ends).
-    gin0 = None
-    if persistent and model.hidden_dim == 128 and not host.is_cuda and total >= max(1, chunked_upload_min_rows):
-        sd0 = model.state_dict()
-        w0 = torch.cat([sd0["lstm.weight_ih_l0"], sd0["lstm.weight_ih_l0_reverse"]], 0).to(device=device, dtype=torch.float32)
-        b0 = torch.cat([sd0["lstm.bias_ih_l0"] + sd0["lstm.bias_hh_l0"], sd0["lstm.bias_ih_l0_reverse"] + sd0["lstm.bias_hh_l0_reverse"]], 0).to(device=device, dtype=torch.float32)
-        gin0 = torch.empty((total, w0.shape[0]), dtype=torch.float32, device=device)
-        main = torch.cuda.current_stream(device)
-        side = torch.cuda.Stream(device=device)
-        n_chunks = 8
-        step = -(-total // n_chunks)
-        for r0 in range(0, total, step):
-            r1 = min(total, r0 + step)
-            with torch.cuda.stream(side):
-                xc = host[r0:r1].to(device)            # (pageable host memory: the call returns when the chunk is on the device)
-                ev = torch.cuda.Event()
-                ev.record(side)
-            main.wait_event(ev)
-            torch.addmm(b0, xc, w0.t(), out=gin0[r0:r1])
-            xc.record_stream(main)
-        x_file = None
-        mark("h2d_mfcc+input_projection_l0")
-    else:
-        x_file = host.to(device)
-        mark("h2d_mfcc")
+    x_file = torch.as_tensor(data, dtype=torch.float32)[:total].to(device)
+    mark("h2d_mfcc")
     if total == 0:
         return torch.zeros((0, model.dense.out_features), dtype=torch.float32, device=device)
     starts = np.concatenate([[0], ends[:-1]])
@@ -129,8 +102,6 @@ def lstm_logits_device(model, data, indices, device=None, persistent=True, timin
         # row order, only the small per-segment tables are sorted (a tile of 32 runs for its longest member)
         offs = starts[order]
         x, perm = x_file, None
-    elif x_file is None:
-        raise AssertionError("chunked upload is the persistent path's")
     else:
         offs = np.concatenate([[0], np.cumsum(slen)[:-1]])  # row offsets in the length-sorted layout
         # sorted row r of segment i (sorted position s): file row starts[order[s]] + (r - offs[s])
@@ -155,11 +126,8 @@ def lstm_logits_device(model, data, indices, device=None, persistent=True, timin
         w_ih = torch.cat([sd["lstm.weight_ih" + s] for s in sfx], 0)                       # [8H, in]
         bias = torch.cat([sd["lstm.bias_ih" + s] + sd["lstm.bias_hh" + s] for s in sfx], 0)  # [8H]
         w_hh_t = torch.stack([sd["lstm.weight_hh" + s].t().contiguous() for s in sfx], 0)  # [2, H, 4H]
-        if layer == 0 and gin0 is not None:
-            gin = gin0                                                                     # projected while it was uploaded
-        else:
-            gin = torch.addmm(bias, inp, w_ih.t())                                         # [total, 8H]
-            mark(f"input_projection_l{layer}")
+        gin = torch.addmm(bias, inp, w_ih.t())                                             # [total, 8H]
+        mark(f"input_projection_l{layer}")
         out = torch.empty((total, 2 * H), dtype=torch.float32, device=device)
         if persistent:
             # the whole layer in one launch: ka_lstm_layer_f32 (f32 MFMA, W_hh register-resident, h in LDS)

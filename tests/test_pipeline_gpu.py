@@ -114,10 +114,6 @@ def test_persistent_lstm_many_tiles_and_empty_segments():
     b = lstm_logits_device(model, data, np.cumsum(lens), persistent=False)
     assert a.shape == b.shape == (int(lens.sum()), 39)
     np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=1e-4)
-    # the chunked upload (rows go up in 8 pieces on a second stream, each projected while the next is on its way) is the
-    # same arithmetic row by row (the library may tile a chunk's GEMM differently: float32 rounding only)
-    c = lstm_logits_device(model, data, np.cumsum(lens), persistent=True, chunked_upload_min_rows=1)
-    np.testing.assert_allclose(a.cpu().numpy(), c.cpu().numpy(), rtol=0, atol=1e-5)
 
 
 def test_best_path_stage_keeps_per_file_progress_when_a_chapter_fails(tmp_path):
