@@ -258,11 +258,6 @@ __device__ __forceinline__ void tp_frame(TpTile<M, ZL> &c, uint32_t t, float (&H
                                          uint32_t h2, float NINF)
 {
     const bool live = !GUARDED || ((int32_t)t >= c.t_in && (int32_t)t < c.t_end);
-    // LDS reads of frame t+2 (skipped frames read too: they prime the pipeline)
-    TpIn far;
-    far.E = f32x2{lds_f32(r2_l0), lds_f32(r2_l1)};
-    far.e0 = lds_f32(r2_0);
-    far.hp = lds_f32x4(h2);
     if (live) {
         const float b0 = c.S[0], b1 = c.S[1], l0 = c.S[2], l1 = c.S[3];
         f32x2 ml, mb;
@@ -297,6 +292,14 @@ __device__ __forceinline__ void tp_frame(TpTile<M, ZL> &c, uint32_t t, float (&H
     // (staged: every lane drops its four cells into this frame's 1-KB row of the LDS staging area - no EXEC change and
     //  no vector-memory instruction per frame; lane 63's go out at the end of the block, tp_publish_block)
     if (live) *(__attribute__((address_space(3))) f32x4 *)(uintptr_t)(c.lds_stage + F * 16) = c.S;
+    // LDS reads of frame t+2 (skipped frames read too: they prime the pipeline).  At the END of the frame, behind the branch
+    // merge above: hipcc waits with lgkmcnt(0) at every merge (the band visit, the guarded frames), and with the reads at the
+    // top of the frame that wait covered reads issued a dozen instructions earlier - every frame stalled for most of an LDS
+    // round trip.  Down here the wait of the next frame finds reads that are a whole frame old.
+    TpIn far;
+    far.E = f32x2{lds_f32(r2_l0), lds_f32(r2_l1)};
+    far.e0 = lds_f32(r2_0);
+    far.hp = lds_f32x4(h2);
     cur = nxt;
     nxt = far;
 }
