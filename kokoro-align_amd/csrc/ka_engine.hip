@@ -1191,7 +1191,7 @@ int ka_debug_tile_stats(ka_engine *e, uint64_t *out, int32_t max_tasks)
         o[2] |= (st[i].phase[2] >> 32) << 32;      // (two-wavefront tiles: HW_ID of the compute wavefront in the high half of t_in)
         if ((e->verify & 4) && (i == 0 || i == 10 || i == 20)) std::fprintf(stderr, "[ka_debug_tile_stats] ticket %zu cycles per phase: wait %llu, check+sum %llu, progress %llu, requests %llu, publish %llu\n", i,
                                  (unsigned long long)(uint32_t)st[i].phase[0], (unsigned long long)(st[i].phase[0] >> 32), (unsigned long long)(uint32_t)st[i].phase[1],
-                                 (unsigned long long)(st[i].phase[1] >> 32), (unsigned long long)st[i].phase[2]);
+                                 (unsigned long long)(st[i].phase[1] >> 32), (unsigned long long)(uint32_t)st[i].phase[2]);
     }
     return (int)n;
 }
