@@ -161,6 +161,10 @@ int ka_engine_set_backtrace(ka_engine *e, int32_t how);
  * first, run the longest n_tiled in the tiled form and walk the longest n_parallel back chunk-parallel instead of asking
  * the cost model (ka_engine.hip); -1 = the cost model.  Results are identical whatever the split. */
 int ka_debug_set_split(ka_engine *e, int32_t n_tiled, int32_t n_parallel);
+/* Host-side probe of that cost model (no GPU needed): for a launch of n lattices of T[i] frames whose band keeps
+ * `tiles_alive` tiles running at once (5 for the reference's beam of 1000) on a device of n_simd SIMDs, how many of the
+ * longest it runs tiled and how many it walks back chunk-parallel. */
+int ka_debug_auto_split(const int64_t *T, int32_t n, int32_t tiles_alive, int32_t n_simd, int32_t *n_tiled, int32_t *n_parallel);
 /* LDS bytes a tile workgroup of the tiled form requests (0 = the library's choice; 40 KB lets four workgroups share a CU, 80 KB
  * two): an occupancy experiment knob, results are identical. */
 int ka_debug_set_tile_lds(ka_engine *e, int32_t bytes);

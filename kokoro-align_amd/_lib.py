@@ -35,6 +35,7 @@ EXPORTS = [
     "ka_debug_tile_stats", "ka_engine_set_backtrace", "ka_debug_chunk_entries", "ka_debug_plan_tiles",
     "ka_engine_set_verify", "ka_stream_create", "ka_stream_destroy", "ka_engine_set_tile_waves",
     "ka_debug_set_split", "ka_engine_workspace_bytes", "ka_debug_set_tile_lds",
+    "ka_debug_auto_split",
 ]
 
 
@@ -101,6 +102,8 @@ def load_library():
     L.ka_stream_create.argtypes = [i32, pp]
     L.ka_stream_destroy.restype = ctypes.c_int
     L.ka_stream_destroy.argtypes = [i32, vp]
+    L.ka_debug_auto_split.restype = ctypes.c_int
+    L.ka_debug_auto_split.argtypes = [pi64, i32, i32, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.ka_debug_set_tile_lds.restype = ctypes.c_int
     L.ka_debug_set_tile_lds.argtypes = [vp, i32]
     L.ka_debug_set_split.restype = ctypes.c_int

@@ -496,7 +496,8 @@ int ka_engine_last_kernel_ms(ka_engine *e, float ms[4])
 //   backtrace(m) = max(chain_serial(T_m), parallel(m) + throughput_serial(m))
 // by a scan over the sorted lengths.  The two forms are not independent: they share the SIMDs.  A tile's wavefronts run at
 // the latency of their own instruction stream (55 % of it vector ALU), so w one-wavefront lattices on the same SIMD stretch
-// its frames by tmult = 1 + 0.55 w, and a resident tile stretches a one-wavefront lattice by wmult = 1 + 0.4 (sweep: 300
+// its frames by tmult = 1 + 0.55 w (w averaged over the tile chain's duration: short lattices are gone early), and a resident
+// tile stretches a one-wavefront lattice by wmult = 1 + 0.4 (sweep: 300
 // chapters of 80k-160k frames, the longest 225 tiled: 29 ms against 19 ms all tiled; 2000 chapters of 20k-100k: 28 ms with
 // one wavefront each, 43 ms with the longest 250 tiled).  Mixed launches pay when a few long lattices come with many short
 // ones (40 of 100k-160k + 1500 of 20k-40k: 41 ms one wavefront each, 31 ms all tiled, 21.5 ms with the longest ~100 tiled).
@@ -527,7 +528,11 @@ static int32_t auto_split_forward(const std::vector<int64_t> &T, const std::vect
     for (int32_t i = n - 1; i >= 0; --i) wave_alu[i] = wave_alu[i + 1] + (double)T[i] * kAuto.wave_alu / simds;
     std::vector<double> est(n + 1, 0.0);
     for (int32_t k = 0; k <= n; ++k) {
-        const double tmult = 1.0 + kAuto.tile_stretch * (double)(n - k) / simds;
+        // one-wavefront lattices that share the SIMDs with the tiles, averaged over the tile chain's duration (short ones are
+        // gone long before the longest tiled lattice ends)
+        double w = (double)(n - k) / simds;
+        if (k > 0) w = std::min(w, wave_alu[k] * (kAuto.wave_chain / kAuto.wave_alu) / (kAuto.tile_chain * (double)T[0]));
+        const double tmult = 1.0 + kAuto.tile_stretch * w;
         const double wmult = 1.0 + kAuto.wave_stretch * std::min(1.0, tiles[k] / simds);
         double chain = 0.0;
         if (k > 0) chain = kAuto.tile_chain * (double)T[0] * tmult;
@@ -550,17 +555,15 @@ static int32_t auto_split_backtrace(const std::vector<int64_t> &T, int32_t n_sim
     std::vector<double> par(n + 1, 0.0), ser(n + 1, 0.0);
     for (int32_t i = 0; i < n; ++i) par[i + 1] = par[i] + (double)T[i] * kAuto.par_frame;
     for (int32_t i = n - 1; i >= 0; --i) ser[i] = ser[i + 1] + (double)T[i] * kAuto.serial_thr / (double)n_simd;
-    double best = 0.0;
-    int32_t best_m = 0;
+    std::vector<double> est(n + 1, 0.0);
     for (int32_t m = 0; m <= n; ++m) {
-        double est = (m > 0 ? kAuto.par_fixed + par[m] : 0.0) + ser[m];
-        if (m < n) est = std::max(est, kAuto.serial_chain * (double)T[m]);
-        if (m > 0 && m < n) est += kAuto.fork;
-        if (m == 0 || est < best * 0.97) {
-            best = est;
-            best_m = m;
-        }
+        est[m] = (m > 0 ? kAuto.par_fixed + par[m] : 0.0) + ser[m];
+        if (m < n) est[m] = std::max(est[m], kAuto.serial_chain * (double)T[m]);
+        if (m > 0 && m < n) est[m] += kAuto.fork;
     }
+    const int32_t best_m = (int32_t)(std::min_element(est.begin(), est.end()) - est.begin());
+    if (est[n] <= est[best_m] * 1.05) return n;     // (one form when it is within the model's accuracy of the best mix)
+    if (est[0] <= est[best_m] * 1.05) return 0;
     return best_m;
 }
 
@@ -1170,6 +1173,18 @@ int ka_debug_plan_tiles(int64_t T, int64_t S, int32_t V, int32_t beam_size, int3
     }
     if (checkpoint_pitch) *checkpoint_pitch = (int64_t)sh.ck_pitch;
     return (int)sh.t_in.size();
+}
+
+int ka_debug_auto_split(const int64_t *T, int32_t n, int32_t tiles_alive, int32_t n_simd, int32_t *n_tiled, int32_t *n_parallel)
+{
+    if (n < 0 || (n > 0 && !T) || tiles_alive < 1 || n_simd < 1 || !n_tiled || !n_parallel)
+        return fail(KA_ERR_BAD_ARGS, "ka_debug_auto_split: bad arguments");
+    std::vector<int64_t> Ts(T, T + n);
+    std::sort(Ts.begin(), Ts.end(), [](int64_t a, int64_t b) { return a > b; });
+    std::vector<int32_t> alive((size_t)n, tiles_alive);
+    *n_tiled = auto_split_forward(Ts, alive, n_simd);
+    *n_parallel = auto_split_backtrace(Ts, n_simd);
+    return KA_OK;
 }
 
 int ka_debug_tile_stats(ka_engine *e, uint64_t *out, int32_t max_tasks)
