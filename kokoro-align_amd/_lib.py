@@ -35,7 +35,7 @@ EXPORTS = [
     "ka_debug_tile_stats", "ka_engine_set_backtrace", "ka_debug_chunk_entries", "ka_debug_plan_tiles",
     "ka_engine_set_verify", "ka_stream_create", "ka_stream_destroy", "ka_engine_set_tile_waves",
     "ka_debug_set_split", "ka_engine_workspace_bytes", "ka_debug_set_tile_lds",
-    "ka_debug_auto_split",
+    "ka_debug_auto_split", "ka_debug_set_rc_gather",
 ]
 
 
@@ -104,6 +104,8 @@ def load_library():
     L.ka_stream_destroy.argtypes = [i32, vp]
     L.ka_debug_auto_split.restype = ctypes.c_int
     L.ka_debug_auto_split.argtypes = [pi64, i32, i32, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.ka_debug_set_rc_gather.restype = ctypes.c_int
+    L.ka_debug_set_rc_gather.argtypes = [vp, i32]
     L.ka_debug_set_tile_lds.restype = ctypes.c_int
     L.ka_debug_set_tile_lds.argtypes = [vp, i32]
     L.ka_debug_set_split.restype = ctypes.c_int
@@ -211,6 +213,9 @@ class Engine:
         """Calibration of the AUTO modes: the longest n_tiled lattices of a launch run tiled, the longest n_parallel are walked
         back chunk-parallel; -1 = the library's cost model."""
         check(self.lib.ka_debug_set_split(self.handle, int(n_tiled), int(n_parallel)), "ka_debug_set_split")
+
+    def set_rc_gather(self, how):
+        check(self.lib.ka_debug_set_rc_gather(self.handle, int(how)), "ka_debug_set_rc_gather")
 
     def set_tile_lds(self, nbytes):
         check(self.lib.ka_debug_set_tile_lds(self.handle, int(nbytes)), "ka_debug_set_tile_lds")

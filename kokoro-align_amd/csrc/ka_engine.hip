@@ -189,6 +189,7 @@ struct ka_engine {
     int32_t last_V = 0, last_beam = 0, last_max_move = 0, last_mem = KA_MEM_DEVICE;
     int32_t verify = 0;                    // ka_engine_set_verify: self-checks of the tiled form's hand-off
     int32_t tile_waves = 2;                // ka_engine_set_tile_waves: wavefronts per tile of the tiled form
+    int32_t rc_gather = -1;                // ka_debug_set_rc_gather: -1 the library's rule, 0 / 1 the serial backtrace's output form
     int32_t tile_lds = 0;                  // ka_debug_set_split's third knob: LDS bytes a tile workgroup requests (0: kTpLdsRequest)
     int32_t split_tiled = -1, split_par = -1;   // ka_debug_set_split: how many of the longest lattices run tiled / are walked back chunk-parallel (-1: cost model)
     hipStream_t aux = nullptr;             // second stream: the other kernel form of a mixed launch runs beside the first
@@ -272,11 +273,17 @@ void launch_forward_flagged(const ka::Lattice *d_lats, int n, int32_t *d_meta, h
     hipLaunchKernelGGL((ka::forward_w16_kernel<M, true>), dim3(n), dim3(64), 0, s, d_lats, d_meta, 1);
 }
 
+// gather: the serial walk of at least a wavefront per SIMD fetches labels and scores after the walk (backtrace_rc_kernel<.., GO>)
 template <int M>
-void launch_backtrace_rc(const ka::Lattice *d_lats, int n, int32_t *d_meta, hipStream_t s)
+void launch_backtrace_rc(const ka::Lattice *d_lats, int n, int32_t *d_meta, hipStream_t s, bool gather)
 {
-    hipLaunchKernelGGL((ka::backtrace_rc_kernel<M, false, false>), dim3(n), dim3(64), 0, s, d_lats, d_meta, n);
-    hipLaunchKernelGGL((ka::backtrace_rc_kernel<M, true, false>), dim3(n), dim3(64), 0, s, d_lats, d_meta, n);
+    if (gather) {
+        hipLaunchKernelGGL((ka::backtrace_rc_kernel<M, false, false, true>), dim3(n), dim3(64), 0, s, d_lats, d_meta, n);
+        hipLaunchKernelGGL((ka::backtrace_rc_kernel<M, true, false, true>), dim3(n), dim3(64), 0, s, d_lats, d_meta, n);
+    } else {
+        hipLaunchKernelGGL((ka::backtrace_rc_kernel<M, false, false, false>), dim3(n), dim3(64), 0, s, d_lats, d_meta, n);
+        hipLaunchKernelGGL((ka::backtrace_rc_kernel<M, true, false, false>), dim3(n), dim3(64), 0, s, d_lats, d_meta, n);
+    }
 }
 
 }  // namespace
@@ -434,6 +441,13 @@ int ka_engine_set_verify(ka_engine *e, int32_t flags)
     if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
     if (flags < 0 || flags > 7) return fail(KA_ERR_BAD_ARGS, "ka_engine_set_verify: flags are a combination of 1, 2 and 4");
     e->verify = flags;
+    return KA_OK;
+}
+
+int ka_debug_set_rc_gather(ka_engine *e, int32_t how)
+{
+    if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
+    e->rc_gather = how < 0 ? -1 : (how ? 1 : 0);
     return KA_OK;
 }
 
@@ -995,11 +1009,12 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
         if (n_par < nl) {      // one wavefront per lattice, chunk after chunk (skips the chunk-parallel ones)
             if (two_backtraces) KA_HIP(fork(2));
             hipStream_t ss = two_backtraces ? e->aux : stream;
+            const bool gather = e->rc_gather >= 0 ? e->rc_gather != 0 : (nl - n_par >= e->n_simd);
             switch (max_move) {
-            case 1: launch_backtrace_rc<1>(d_lats + rc_lo, nl, d_meta, ss); break;
-            case 2: launch_backtrace_rc<2>(d_lats + rc_lo, nl, d_meta, ss); break;
-            case 3: launch_backtrace_rc<3>(d_lats + rc_lo, nl, d_meta, ss); break;
-            default: launch_backtrace_rc<4>(d_lats + rc_lo, nl, d_meta, ss); break;
+            case 1: launch_backtrace_rc<1>(d_lats + rc_lo, nl, d_meta, ss, gather); break;
+            case 2: launch_backtrace_rc<2>(d_lats + rc_lo, nl, d_meta, ss, gather); break;
+            case 3: launch_backtrace_rc<3>(d_lats + rc_lo, nl, d_meta, ss, gather); break;
+            default: launch_backtrace_rc<4>(d_lats + rc_lo, nl, d_meta, ss, gather); break;
             }
         }
         if (n_par > 0) {

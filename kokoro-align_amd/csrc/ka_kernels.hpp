@@ -1660,7 +1660,14 @@ __device__ __forceinline__ void rc_walk_out(const uint32_t (&codes)[kCkFrames / 
 // PAR = false: one wavefront per lattice walks its chunks from the last to the first (the position a chunk is entered
 // at comes out of the chunk above it).  PAR = true: one wavefront per CHUNK, entered at Lattice::entry[chunk], which the
 // chunk-parallel backtrace (ka_parallel_bt.hpp) has worked out for every chunk beforehand; grid = all chunks of the launch.
-template <int M, bool ZL, bool PAR>
+// GO ("gather the outputs"): the walk collects the path only, and best_labels / best_scores are fetched afterwards, lane f
+// doing frame t0+f - the label with one ds_bpermute on the window's label register, the score with ONE 4-byte load per frame
+// from the row this wavefront read a few microseconds ago (L2 / Infinity Cache).  Four vector instructions per frame fewer
+// (two v_readlane + two v_writelane of the walk) for one gather per chunk whose latency other wavefronts cover: the form for
+// launches that fill the chip, where the step is bound by the number of vector instructions.  GO = false
+// keeps everything in registers: the form for few lattices, where a chunk is a serial chain and a memory round trip per
+// chunk would lengthen it by a third.
+template <int M, bool ZL, bool PAR, bool GO = false>
 __global__ __launch_bounds__(64, KA_RC_MIN_WAVES) void backtrace_rc_kernel(const Lattice *__restrict__ lats, const int32_t *meta, int n_lats)
 {
     const int which = PAR ? __builtin_amdgcn_readfirstlane(lattice_of_chunk(lats, n_lats, (int64_t)blockIdx.x)) : (int)blockIdx.x;
@@ -1859,16 +1866,33 @@ __global__ __launch_bounds__(64, KA_RC_MIN_WAVES) void backtrace_rc_kernel(const
         int qq = p - wlo;
         // best_path, best_labels = lab'[best_path], best_scores[t] = lp[t, best_labels[t]] (align.py:105-107), lane f
         // does frame t0+f: collected by the walk itself (rc_walk_out)
-        int labv = 0;
-        float scv = 0.0f;
-        if (n == kCkFrames)
-            rc_walk_out<true>(codes, rows, lab4, n, qq, pathv, labv, scv);
-        else
-            rc_walk_out<false>(codes, rows, lab4, n, qq, pathv, labv, scv);
-        if (lane < n) {
-            path[t0 + lane] = pathv + wlo;
-            lab_out[t0 + lane] = labv;
-            sc_out[t0 + lane] = scv;
+        if constexpr (GO) {
+            if (n == kCkFrames)
+                rc_walk<true>(codes, n, qq, pathv);
+            else
+                rc_walk<false>(codes, n, qq, pathv);
+            // lane f: position wlo + pathv; its label sits in lane (pathv >> 1) of the window's label register (odd positions)
+            const int lw = __builtin_amdgcn_ds_bpermute((pathv >> 1) * 4, lab4);
+            if (lane < n) {
+                const int pos = pathv + wlo;
+                const int l4 = (pos & 1) ? lw : 0;
+                const float sv = *(gcf32_t)(lp + (size_t)(t0 + (uint32_t)lane) * ldb + (uint32_t)l4);
+                path[t0 + lane] = pos;
+                lab_out[t0 + lane] = l4 >> 2;
+                sc_out[t0 + lane] = sv;
+            }
+        } else {
+            int labv = 0;
+            float scv = 0.0f;
+            if (n == kCkFrames)
+                rc_walk_out<true>(codes, rows, lab4, n, qq, pathv, labv, scv);
+            else
+                rc_walk_out<false>(codes, rows, lab4, n, qq, pathv, labv, scv);
+            if (lane < n) {
+                path[t0 + lane] = pathv + wlo;
+                lab_out[t0 + lane] = labv;
+                sc_out[t0 + lane] = scv;
+            }
         }
         p = qq + wlo;
         if (PAR || t0 == 0) break;

@@ -371,3 +371,23 @@ def test_corpus_under_auto_sample_vs_oracle_and_properties_on_all():
     finally:
         eng.set_split(-1, -1)
         _set(eng, "auto")
+
+
+@pytest.mark.parametrize("gather", [0, 1])
+def test_serial_backtrace_output_forms_on_a_book(books_on_device, gather):
+    """backtrace_rc_kernel<.., GO>: labels and scores collected by the walk in registers (few lattices) or gathered from memory
+    after it (launches that fill the chip; ka_debug_set_rc_gather forces either): the same three outputs, bit for bit."""
+    from kokoro_align_amd.align import DeviceBatch
+    lps, labs = books_on_device("kokoro")
+    want = _oracle("kokoro")
+    eng = _engine()
+    try:
+        for mode in ("wave", "tiled"):
+            _set(eng, mode)
+            eng.set_rc_gather(gather)
+            b = DeviceBatch(lps, labs)
+            b.run()
+            _check_against_oracle(b, want)
+    finally:
+        eng.set_rc_gather(-1)
+        _set(eng, "auto")

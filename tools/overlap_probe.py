@@ -42,6 +42,7 @@ def run(G, stagger_ms, period_ms=72.0):
         b.engine.set_mode(os.environ.get("PROBE_MODE", "wave"))
         b.engine.set_backtrace(os.environ.get("PROBE_BACKTRACE", "serial"))
         b.engine.set_profiling(os.environ.get("PROBE_PROFILING", "0") == "1")
+        b.engine.set_rc_gather(int(os.environ.get("PROBE_RC_GATHER", "-1")))
         b.engine.reserve(b.workspace_bytes() + (1 << 20))
         batches.append(b)
         if os.environ.get("PROBE_OWN_STREAMS", "1") == "1":
