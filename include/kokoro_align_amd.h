@@ -169,8 +169,8 @@ int ka_debug_auto_split(const int64_t *T, int32_t n, int32_t tiles_alive, int32_
  * two): an occupancy experiment knob, results are identical. */
 int ka_debug_set_tile_lds(ka_engine *e, int32_t bytes);
 /* The serial backtrace's output form: 1 = labels and scores gathered from memory after the walk (fewer vector instructions:
- * launches that fill the chip), 0 = collected by the walk in registers (no memory round trip per chunk: few lattices),
- * -1 = the library's rule (gather from one wavefront per SIMD upwards).  Results are identical. */
+ * launches that fill the chip; by the counters 17 % more HBM traffic per step), 0 or -1 (default) = collected by the walk in
+ * registers.  Results are identical. */
 int ka_debug_set_rc_gather(ka_engine *e, int32_t how);
 /* Wavefronts per tile of the tiled form: 2 (default; ka_tiled2.hpp: one wavefront runs the frames, the other stages rows and
  * halo packets, polls, publishes) or 1 (ka_tiled.hpp: one wavefront does both).  Results are identical. */

@@ -1009,7 +1009,9 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
         if (n_par < nl) {      // one wavefront per lattice, chunk after chunk (skips the chunk-parallel ones)
             if (two_backtraces) KA_HIP(fork(2));
             hipStream_t ss = two_backtraces ? e->aux : stream;
-            const bool gather = e->rc_gather >= 0 ? e->rc_gather != 0 : (nl - n_par >= e->n_simd);
+            // (the gather form is opt-in: 27.2 -> 26.1 ms for 8192 lattices alone on the GPU, nothing with four launches in flight,
+            //  and 47 GB more HBM traffic per step by the counters - DESIGN.md section 8)
+            const bool gather = e->rc_gather == 1;
             switch (max_move) {
             case 1: launch_backtrace_rc<1>(d_lats + rc_lo, nl, d_meta, ss, gather); break;
             case 2: launch_backtrace_rc<2>(d_lats + rc_lo, nl, d_meta, ss, gather); break;

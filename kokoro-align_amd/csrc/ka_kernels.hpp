@@ -1663,10 +1663,9 @@ __device__ __forceinline__ void rc_walk_out(const uint32_t (&codes)[kCkFrames / 
 // GO ("gather the outputs"): the walk collects the path only, and best_labels / best_scores are fetched afterwards, lane f
 // doing frame t0+f - the label with one ds_bpermute on the window's label register, the score with ONE 4-byte load per frame
 // from the row this wavefront read a few microseconds ago (L2 / Infinity Cache).  Four vector instructions per frame fewer
-// (two v_readlane + two v_writelane of the walk) for one gather per chunk whose latency other wavefronts cover: the form for
-// launches that fill the chip, where the step is bound by the number of vector instructions.  GO = false
-// keeps everything in registers: the form for few lattices, where a chunk is a serial chain and a memory round trip per
-// chunk would lengthen it by a third.
+// (two v_readlane + two v_writelane of the walk) for one gather per chunk whose latency other wavefronts cover.  Opt-in
+// (ka_debug_set_rc_gather): 27.2 -> 26.1 ms for 8192 lattices alone on the GPU, nothing with several launches in flight, and
+// the gathers read 47 GB more per step by the counters.  GO = false, the default, keeps everything in registers.
 template <int M, bool ZL, bool PAR, bool GO = false>
 __global__ __launch_bounds__(64, KA_RC_MIN_WAVES) void backtrace_rc_kernel(const Lattice *__restrict__ lats, const int32_t *meta, int n_lats)
 {
