@@ -348,12 +348,14 @@ def pipeline_entry():
                "end_to_end_ms": (t3 - t0) * 1e3, "frames_per_s_end_to_end": total / (t3 - t0),
                "all_paths_end_at_the_trailing_blank": bool(ok)}
         del b, lps, lp, logits
-    # the recurrence kernel against the f32 MFMA peak (MI355X_MICROARCH.md: 157.3 TFLOP/s)
-    rec = sum(v for k_, v in out["network_stages_ms"].items() if k_.startswith("recurrence"))
-    flops = 2.0 * total * 2 * 2 * 128 * 512      # 2 flop per MAC x frames x directions x layers x (128 x 512)
+    # the recurrence kernel against the f32 MFMA peak (MI355X_MICROARCH.md: 157.3 TFLOP/s); layer 0 carries its K = 40 input
+    # projection inside the step (ka_lstm_layer0_f32)
+    rec = sum(v for k_, v in out["network_stages_ms"].items() if "recurrence" in k_)
+    fused = any(k_.startswith("projection+recurrence") for k_ in out["network_stages_ms"])
+    flops = 2.0 * total * 2 * 2 * 128 * 512 + (2.0 * total * 40 * 1024 if fused else 0.0)   # 2 flop per MAC x frames x directions x layers x (128 x 512)
     out["recurrence"] = {"ms_both_layers": rec, "tflops": flops / (rec * 1e-3) / 1e12, "f32_mfma_peak_tflops": 157.3,
-                         "frac_of_peak": flops / (rec * 1e-3) / 1e12 / 157.3,
-                         "note": "chain-bound: the longest segment (1199 steps) x 5.4 us per step; 16 sequences per workgroup"}
+                         "frac_of_peak": flops / (rec * 1e-3) / 1e12 / 157.3, "layer0_projection_inside": fused,
+                         "note": "chain-bound: the longest segment (1199 steps) x 5.4 us per step (6.6 with the layer-0 projection); 16 sequences per workgroup"}
     torch.cuda.empty_cache()
     return out
 

@@ -235,6 +235,11 @@ int ka_lstm_step_f32(const float *gin, int64_t ldg, const float *rec, int64_t re
  */
 int ka_lstm_layer_f32(const float *gin, int64_t ldg, const float *w_hh, float *out, int64_t ldo, const int32_t *seq_off,
                       const int32_t *seq_len, int32_t nseq, int32_t H, void *stream);
+/* The FIRST layer with its input projection inside the step (n_in = 40 MFCC coefficients, train.py:54-65 `n_mfcc`): x [frames,
+ * ldx >= 40] instead of gin; w_ih [2][4H][40] = weight_ih of the two directions, bias [2][4H] = bias_ih + bias_hh.  The
+ * [frames, 8H] projection is never materialised (11 GB for an 8.8-hour book).  Otherwise as ka_lstm_layer_f32. */
+int ka_lstm_layer0_f32(const float *x, int64_t ldx, int32_t n_in, const float *w_ih, const float *bias, const float *w_hh, float *out, int64_t ldo,
+                       const int32_t *seq_off, const int32_t *seq_len, int32_t nseq, int32_t H, void *stream);
 
 /*
  * Audio front end (kokoro_align/preprocess.py:51-131).  Device pointers throughout.

@@ -35,7 +35,7 @@ EXPORTS = [
     "ka_debug_tile_stats", "ka_engine_set_backtrace", "ka_debug_chunk_entries", "ka_debug_plan_tiles",
     "ka_engine_set_verify", "ka_stream_create", "ka_stream_destroy", "ka_engine_set_tile_waves",
     "ka_debug_set_split", "ka_engine_workspace_bytes", "ka_debug_set_tile_lds",
-    "ka_debug_auto_split", "ka_debug_set_rc_gather",
+    "ka_debug_auto_split", "ka_debug_set_rc_gather", "ka_lstm_layer0_f32",
 ]
 
 
@@ -128,6 +128,8 @@ def load_library():
     L.ka_log_softmax_f32.argtypes = [vp, vp, i64, i32, i64, i64, vp]
     L.ka_lstm_layer_f32.restype = ctypes.c_int
     L.ka_lstm_layer_f32.argtypes = [vp, i64, vp, vp, i64, vp, vp, i32, i32, vp]
+    L.ka_lstm_layer0_f32.restype = ctypes.c_int
+    L.ka_lstm_layer0_f32.argtypes = [vp, i64, i32, vp, vp, vp, vp, i64, vp, vp, i32, i32, vp]
     L.ka_lstm_step_f32.restype = ctypes.c_int
     L.ka_lstm_step_f32.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, i64, vp, i64, i32, i32, vp]
     L.ka_window_energy_f32.restype = ctypes.c_int

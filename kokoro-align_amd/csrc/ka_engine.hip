@@ -1262,8 +1262,22 @@ int ka_lstm_layer_f32(const float *gin, int64_t ldg, const float *w_hh, float *o
         return fail(KA_ERR_BAD_ARGS, "ka_lstm_layer_f32: bad arguments");
     if (H != ka::kLstmH) return fail(KA_ERR_BAD_ARGS, "ka_lstm_layer_f32: the persistent kernel is built for hidden size 128");
     if (nseq == 0) return KA_OK;
-    hipLaunchKernelGGL(ka::lstm_layer_kernel, dim3(2u * (unsigned)((nseq + ka::kLstmTile - 1) / ka::kLstmTile)), dim3(256), 0, (hipStream_t)stream, gin, ldg, w_hh,
-                       out, ldo, seq_off, seq_len, nseq);
+    hipLaunchKernelGGL(ka::lstm_layer_kernel<false>, dim3(2u * (unsigned)((nseq + ka::kLstmTile - 1) / ka::kLstmTile)), dim3(256), 0, (hipStream_t)stream, gin, ldg, w_hh,
+                       out, ldo, seq_off, seq_len, nseq, (const float *)nullptr, (const float *)nullptr);
+    KA_HIP(hipGetLastError());
+    return KA_OK;
+}
+
+int ka_lstm_layer0_f32(const float *x, int64_t ldx, int32_t n_in, const float *w_ih, const float *bias, const float *w_hh, float *out, int64_t ldo,
+                       const int32_t *seq_off, const int32_t *seq_len, int32_t nseq, int32_t H, void *stream)
+{
+    if (!x || !w_ih || !bias || !w_hh || !out || !seq_off || !seq_len || nseq < 0 || ldx < n_in || ldo < 2 * (int64_t)H)
+        return fail(KA_ERR_BAD_ARGS, "ka_lstm_layer0_f32: bad arguments");
+    if (H != ka::kLstmH || n_in != ka::kLstmIn)
+        return fail(KA_ERR_BAD_ARGS, "ka_lstm_layer0_f32: built for hidden size 128 and 40 input features");
+    if (nseq == 0) return KA_OK;
+    hipLaunchKernelGGL(ka::lstm_layer_kernel<true>, dim3(2u * (unsigned)((nseq + ka::kLstmTile - 1) / ka::kLstmTile)), dim3(256), 0, (hipStream_t)stream, x, ldx, w_hh,
+                       out, ldo, seq_off, seq_len, nseq, w_ih, bias);
     KA_HIP(hipGetLastError());
     return KA_OK;
 }

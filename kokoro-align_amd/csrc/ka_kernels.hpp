@@ -2113,10 +2113,17 @@ constexpr int kLstmWAcc = 30;          // k-steps whose 8 W fragments live in AG
 #define KA_MFMA_VGPR(ACC, A, W) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(W))
 // grid.x = 2 * ceil(nseq / 16): workgroup id>>1 = tile (longest sequences first, so the dispatcher starts the
 // long tiles first and back-fills the CUs with short ones), id&1 = direction
+// XIN = false: `gin` holds the input projections x W_ih^T + b_ih + b_hh of every frame (one library GEMM per layer).
+// XIN = true (layer 0, kLstmIn = 40 input features): `gin` IS x [frames, ldg >= 40]; the projection runs inside the step - 80
+// more MFMAs (K = 40: 10 k-steps x 8 fragments, W_ih's fragments resident in VGPRs like W_hh's in AGPRs) on top of the 256 of
+// h W_hh^T, the bias is the accumulator's initial value - so the [frames, 1024] projection (11 GB for an 8.8-hour book) is
+// never written or read, and a step prefetches 10 dwords per lane instead of 32.
+constexpr int kLstmIn = 40;
+template <bool XIN>
 __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const float *__restrict__ gin, int64_t ldg,
                                                             const float *__restrict__ w_hh, float *__restrict__ out, int64_t ldo,
                                                             const int32_t *__restrict__ seq_off, const int32_t *__restrict__ seq_len,
-                                                            int nseq)
+                                                            int nseq, const float *__restrict__ w_ih, const float *__restrict__ bias)
 {
     // h of the tile's 16 sequences, double-buffered; within a row unit k sits at (k&3)*32 + (k>>2), so the 32
     // A operands of a lane (k = 4s + kq, s = 0..31) are contiguous: 8 ds_read_b128 per step
@@ -2135,6 +2142,26 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const float *__restr
 #pragma unroll
             for (int s = 0; s < 32; ++s)
                 wreg[g][ct][s] = w_hh[((size_t)dir * 4 * kLstmH + (size_t)g * kLstmH + jbase + 16 * ct + col) * kLstmH + 4 * s + kq];
+    // XIN: W_ih's fragments B[k = 4s+kq][n = col] = W_ih[dir][g*H + jbase + 16ct + col][k], the bias of the lane's columns, and the
+    // sequence whose x row is this lane's A operand (row `col` of the tile)
+    float wih[4][2][kLstmIn / 4], bs[4][2];
+    int lenA = 0, rowbaseA = 0;
+    if constexpr (XIN) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const size_t wrow = (size_t)dir * 4 * kLstmH + (size_t)g * kLstmH + jbase + 16 * ct + col;
+                bs[g][ct] = bias[wrow];
+#pragma unroll
+                for (int s = 0; s < kLstmIn / 4; ++s) wih[g][ct][s] = w_ih[wrow * kLstmIn + 4 * s + kq];
+            }
+        const int i = tile0 + col;
+        const int l = i < nseq ? seq_len[i] : 0;
+        const int o = i < nseq ? seq_off[i] : 0;
+        lenA = l;
+        rowbaseA = l <= 0 ? 0 : dir == 0 ? o : o + l - 1;
+    }
     // the 4 sequences (rows 4kq .. 4kq+3 of the C tile) this lane updates
     int rowbase[4], len[4];
 #pragma unroll
@@ -2164,32 +2191,65 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_kernel(const float *__restr
         const int k = max(min(t, len[r] - 1), 0);
         return gcol + (size_t)(dir == 0 ? rowbase[r] + k : rowbase[r] - k) * (size_t)ldg;
     };
+    auto x_row = [&](int t) {       // XIN: the row of sequence `col` at step t, columns kq, kq+4, ...
+        const int k = max(min(t, lenA - 1), 0);
+        return gin + (size_t)(dir == 0 ? rowbaseA + k : rowbaseA - k) * (size_t)ldg + kq;
+    };
     f32x4 nxt[4][2];
+    float xn[kLstmIn / 4];
+    if constexpr (XIN) {
+        const float *xp = x_row(0);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float *gp = gin_row(r, 0);
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) nxt[g][ct][r] = gp[(size_t)g * kLstmH + 16 * ct];
-    }
-    for (int t = 0; t < tile_len; ++t) {
-        const int cur = t & 1;
-        f32x4 acc[4][2];
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) acc[g][ct] = nxt[g][ct];
+        for (int s = 0; s < kLstmIn / 4; ++s) xn[s] = xp[4 * s];
+    } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float *gp = gin_row(r, t + 1);
+            const float *gp = gin_row(r, 0);
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) nxt[g][ct][r] = gp[(size_t)g * kLstmH + 16 * ct];
         }
+    }
+    for (int t = 0; t < tile_len; ++t) {
+        const int cur = t & 1;
+        f32x4 acc[4][2];
+        float xa[kLstmIn / 4];
+        if constexpr (XIN) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) acc[g][ct] = f32x4{bs[g][ct], bs[g][ct], bs[g][ct], bs[g][ct]};
+            const float *xp = x_row(t + 1);
+#pragma unroll
+            for (int s = 0; s < kLstmIn / 4; ++s) {
+                xa[s] = xn[s];
+                xn[s] = xp[4 * s];
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) acc[g][ct] = nxt[g][ct];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float *gp = gin_row(r, t + 1);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) nxt[g][ct][r] = gp[(size_t)g * kLstmH + 16 * ct];
+            }
+        }
         const f32x4 *arow = reinterpret_cast<const f32x4 *>(&s_h[cur][col][kq * 32]);
         asm volatile("s_nop 3" ::: "memory");   // VALU-written accumulators -> first MFMA
+        if constexpr (XIN) {
+#pragma unroll
+            for (int s = 0; s < kLstmIn / 4; ++s)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) KA_MFMA_VGPR(acc[g][ct], xa[s], wih[g][ct][s]);
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const f32x4 a4 = arow[q];

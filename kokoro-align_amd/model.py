@@ -52,7 +52,7 @@ def segment_logits(model, segments, device=None, batch_size=128):
 
 
 @torch.no_grad()
-def lstm_logits_device(model, data, indices, device=None, persistent=True, timings=None):
+def lstm_logits_device(model, data, indices, device=None, persistent=True, timings=None, fuse_layer0=True):
     """Logits of every frame of an IndexDataArray (``data`` [rows, n_mfcc], ``indices`` = cumulative segment ends,
     kokoro_align/preprocess.py:12-35), [rows, vocab] on ``device`` in the file's row order - what the reference's
     predict() writes to *.logits.npz (train.py:215-231) - computed for ALL segments at once.
@@ -126,9 +126,19 @@ def lstm_logits_device(model, data, indices, device=None, persistent=True, timin
         w_ih = torch.cat([sd["lstm.weight_ih" + s] for s in sfx], 0)                       # [8H, in]
         bias = torch.cat([sd["lstm.bias_ih" + s] + sd["lstm.bias_hh" + s] for s in sfx], 0)  # [8H]
         w_hh_t = torch.stack([sd["lstm.weight_hh" + s].t().contiguous() for s in sfx], 0)  # [2, H, 4H]
+        out = torch.empty((total, 2 * H), dtype=torch.float32, device=device)
+        if persistent and layer == 0 and fuse_layer0 and inp.shape[1] == 40:
+            # layer 0: the input projection (K = 40) runs inside the recurrence kernel - no [total, 8H] intermediate
+            w_hh = torch.stack([sd["lstm.weight_hh" + s] for s in sfx], 0).contiguous()      # [2, 4H, H]
+            w_ih_c = w_ih.contiguous()                                                       # [2 * 4H, 40]
+            _lib.check(lib.ka_lstm_layer0_f32(inp.data_ptr(), inp.stride(0), 40, w_ih_c.data_ptr(), bias.data_ptr(), w_hh.data_ptr(),
+                                              out.data_ptr(), out.stride(0), d_offs32.data_ptr(), d_len32.data_ptr(), n, H, stream),
+                       "ka_lstm_layer0_f32")
+            mark(f"projection+recurrence_l{layer}")
+            inp = out
+            continue
         gin = torch.addmm(bias, inp, w_ih.t())                                             # [total, 8H]
         mark(f"input_projection_l{layer}")
-        out = torch.empty((total, 2 * H), dtype=torch.float32, device=device)
         if persistent:
             # the whole layer in one launch: ka_lstm_layer_f32 (f32 MFMA, W_hh register-resident, h in LDS)
             w_hh = torch.stack([sd["lstm.weight_hh" + s] for s in sfx], 0).contiguous()      # [2, 4H, H]

@@ -114,6 +114,9 @@ def test_persistent_lstm_many_tiles_and_empty_segments():
     b = lstm_logits_device(model, data, np.cumsum(lens), persistent=False)
     assert a.shape == b.shape == (int(lens.sum()), 39)
     np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=1e-4)
+    # layer 0 with its input projection inside the recurrence kernel (the default) against the library GEMM in front of it
+    c = lstm_logits_device(model, data, np.cumsum(lens), persistent=True, fuse_layer0=False)
+    np.testing.assert_allclose(a.cpu().numpy(), c.cpu().numpy(), rtol=0, atol=2e-5)
 
 
 def test_best_path_stage_keeps_per_file_progress_when_a_chapter_fails(tmp_path):
