@@ -401,7 +401,9 @@ def main():
     rank_env = int(os.environ.get("RANK", "0"))
     cpu = None
     if rank_env == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.cpu_baseline_seconds)
+        # (under a launcher with several ranks only the one-core figures: the others are waiting for rank 0 in the process
+        #  group's rendezvous, and the 16-process pool belongs to the parent of relay_to_children, which has no ranks waiting)
+        cpu = cpu_baseline(args.cpu_baseline_seconds, share=world_env <= 1)
 
     # stdout must carry exactly ONE JSON line: native libraries (RCCL prints a version banner) write to
     # fd 1 directly, so point fd 1 at stderr until the result is printed
