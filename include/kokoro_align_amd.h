@@ -168,6 +168,10 @@ int ka_debug_auto_split(const int64_t *T, int32_t n, int32_t tiles_alive, int32_
 /* LDS bytes a tile workgroup of the tiled form requests (0 = the library's choice; 40 KB lets four workgroups share a CU, 80 KB
  * two): an occupancy experiment knob, results are identical. */
 int ka_debug_set_tile_lds(ka_engine *e, int32_t bytes);
+/* Positions per tile of the tiled form: 256 (four cells per lane), 128 (two: ka_tiled_narrow.hpp, a shorter frame and twice
+ * the tiles; only with two wavefronts per tile), or 0 = the library's choice (128 when all the launch's tiles are alive on
+ * no more than half the device's SIMDs).  Results are identical. */
+int ka_debug_set_tile_width(ka_engine *e, int32_t positions);
 /* The serial backtrace's output form: 1 = labels and scores gathered from memory after the walk (fewer vector instructions:
  * launches that fill the chip; by the counters 17 % more HBM traffic per step), 0 or -1 (default) = collected by the walk in
  * registers.  Results are identical. */
@@ -196,6 +200,9 @@ int ka_debug_chunk_entries(ka_engine *e, int32_t *out, int32_t max_entries, uint
  * a negative status for bad arguments.  checkpoint_pitch (may be NULL): bytes per checkpoint row. */
 int ka_debug_plan_tiles(int64_t T, int64_t S, int32_t V, int32_t beam_size, int32_t max_move, int32_t *t_in, int32_t *t_end,
                         int32_t max_tiles, int64_t *checkpoint_pitch);
+/* The same for tiles of `positions` = 128 or 256 positions (ka_debug_set_tile_width). */
+int ka_debug_plan_tiles_width(int64_t T, int64_t S, int32_t V, int32_t beam_size, int32_t max_move, int32_t positions, int32_t *t_in,
+                              int32_t *t_end, int32_t max_tiles, int64_t *checkpoint_pitch);
 int ka_engine_set_profiling(ka_engine *e, int32_t on);
 int ka_engine_last_kernel_ms(ka_engine *e, float ms[4]);
 

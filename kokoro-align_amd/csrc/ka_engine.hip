@@ -8,6 +8,7 @@
 #include "ka_kernels.hpp"
 #include "ka_tiled.hpp"
 #include "ka_tiled2.hpp"
+#include "ka_tiled_narrow.hpp"
 #include "ka_parallel_bt.hpp"
 
 #include <algorithm>
@@ -88,15 +89,15 @@ inline size_t par_bt_bytes(const Shape &sh)
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// Which frames each 256-position tile is alive in, from the band of align.py:64-65:
+// Which frames each tile of P positions (256, or 128: ka_tiled_narrow.hpp) is alive in, from the band of align.py:64-65:
 //   lo(t) = max(0, floor(L t / T) - B/2),  hi(t) = min(lo(t) + B, L)
-//   t_in(b)  = first t with hi(t) > 256 b        = 0 if 256 b < B, else ceil((256 b - B + B/2 + 1) T / L)
-//   t_end(b) = first t with lo(t) >= 256 (b+1)   = ceil((256 (b+1) + B/2) T / L), at most T
-void plan_tiles(Shape &sh, int32_t V, int32_t beam, int32_t max_move)
+//   t_in(b)  = first t with hi(t) > P b        = 0 if P b < B, else ceil((P b - B + B/2 + 1) T / L)
+//   t_end(b) = first t with lo(t) >= P (b+1)   = ceil((P (b+1) + B/2) T / L), at most T
+void plan_tiles(Shape &sh, int32_t V, int32_t beam, int32_t max_move, int64_t P = ka::kTpTile)
 {
     sh.tileable = false;
     if (V > 64 || max_move > 4 || beam < 1 || sh.T >= (int64_t(1) << 26)) return;
-    const int64_t T = sh.T, L = sh.L, B = beam, h = B / 2, P = ka::kTpTile;
+    const int64_t T = sh.T, L = sh.L, B = beam, h = B / 2;
     const int64_t n_tiles = ceil_div(L, P);
     sh.t_in.clear();
     sh.t_end.clear();
@@ -107,7 +108,7 @@ void plan_tiles(Shape &sh, int32_t V, int32_t beam, int32_t max_move)
         const int64_t ti = x < B ? 0 : ceil_div((x - B + h + 1) * T, L);
         if (ti >= T) break;
         const int64_t te = std::min<int64_t>(T, ceil_div((z + h) * T, L));
-        if (te <= ti) return;   // the band jumps over a whole tile in one frame (L/T > 256): not worth a pipeline
+        if (te <= ti) return;   // the band jumps over a whole tile in one frame (L/T > P): not worth a pipeline
         sh.t_in.push_back((int32_t)ti);
         sh.t_end.push_back((int32_t)te);
         if (te == T) ++sh.n_final;
@@ -119,7 +120,7 @@ void plan_tiles(Shape &sh, int32_t V, int32_t beam, int32_t max_move)
     // size, or simply the whole label axis when that is not larger
     size_t ring = 1024;
     while (ring < (size_t)sh.W + 512) ring *= 2;
-    const size_t whole = (size_t)ceil_div(L, P) * P;
+    const size_t whole = (size_t)ceil_div(L, ka::kTpTile) * ka::kTpTile;   // (whatever P: the readers' windows may reach up to the next multiple of 256)
     if (whole <= ring) {
         sh.ck_mask = 0xffffffffu;
         sh.ck_pitch = whole * 4;
@@ -190,6 +191,7 @@ struct ka_engine {
     int32_t verify = 0;                    // ka_engine_set_verify: self-checks of the tiled form's hand-off
     int32_t tile_waves = 2;                // ka_engine_set_tile_waves: wavefronts per tile of the tiled form
     int32_t rc_gather = -1;                // ka_debug_set_rc_gather: -1 the library's rule, 0 / 1 the serial backtrace's output form
+    int32_t tile_width = 0;                // ka_debug_set_tile_width: 0 = the engine chooses, 128 or 256
     int32_t tile_lds = 0;                  // ka_debug_set_split's third knob: LDS bytes a tile workgroup requests (0: kTpLdsRequest)
     int32_t split_tiled = -1, split_par = -1;   // ka_debug_set_split: how many of the longest lattices run tiled / are walked back chunk-parallel (-1: cost model)
     hipStream_t aux = nullptr;             // second stream: the other kernel form of a mixed launch runs beside the first
@@ -390,8 +392,14 @@ size_t ka_workspace_bytes(int32_t n, const int64_t *T, const int64_t *S, int32_t
             sh.tiled = true;
             sh.par_bt = true;
             plain = std::max(plain, lattice_ws_bytes(sh));
-            tasks += sh.t_in.size();
+            size_t wide_tasks = sh.t_in.size();
             ninf_slots = std::max<int64_t>(ninf_slots, sh.t_end[0]);
+            plan_tiles(sh, V, beam_size, max_move, ka::kTnTile);   // (the 128-position tiles: twice the boundaries)
+            if (sh.tileable) {
+                plain = std::max(plain, lattice_ws_bytes(sh));
+                wide_tasks = std::max(wide_tasks, sh.t_in.size());
+            }
+            tasks += wide_tasks;
         }
         total += plain;
     }
@@ -464,6 +472,14 @@ int ka_debug_set_split(ka_engine *e, int32_t n_tiled, int32_t n_parallel)
     if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
     e->split_tiled = n_tiled < 0 ? -1 : n_tiled;
     e->split_par = n_parallel < 0 ? -1 : n_parallel;
+    return KA_OK;
+}
+
+int ka_debug_set_tile_width(ka_engine *e, int32_t positions)
+{
+    if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
+    if (positions != 0 && positions != ka::kTnTile && positions != ka::kTpTile) return fail(KA_ERR_BAD_ARGS, "ka_debug_set_tile_width: 0, 128 or 256");
+    e->tile_width = positions;
     return KA_OK;
 }
 
@@ -645,6 +661,38 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
             for (int32_t j = 0; j < k; ++j) sh[cand[j]].tiled = true;
         }
         for (int32_t i = 0; i < n; ++i) n_tiled += sh[i].tiled ? 1 : 0;
+    }
+    // ---- tile width: 128 positions (two cells per lane, ka_tiled_narrow.hpp: a shorter frame, twice the tiles and twice the
+    // hand-offs) while the tiles alive at once are no more than 2.5 per SIMD, else 256.  Measured on prefixes of the corpus
+    // stand-in, all tiled (tools/sweep_width.py, profiles/r03_sweep_width.jsonl): 128 positions are 10-15 % faster up to 200
+    // chapters (~1800 tiles alive), even at 250 (~2250), 4 % slower at 320 (~2900), 15 % slower for all 462.
+    bool narrow = false;
+    if (n_tiled > 0 && e->tile_waves == 2 && e->tile_width != ka::kTpTile) {
+        std::vector<Shape> alt;
+        int64_t alive_now = 0;
+        bool ok = true;
+        for (int32_t i = 0; i < n && ok; ++i) {
+            if (!sh[i].tiled) continue;
+            Shape p = sh[i];
+            plan_tiles(p, V, beam_size, max_move, ka::kTnTile);
+            ok = p.tileable;
+            alive_now += std::min<int64_t>((int64_t)p.t_in.size(), (p.W + 2 * ka::kTnTile - 1) / ka::kTnTile);
+            alt.push_back(std::move(p));
+        }
+        if (ok && (e->tile_width == ka::kTnTile || 2 * alive_now <= 5 * (int64_t)e->n_simd)) {
+            narrow = true;
+            size_t j = 0;
+            for (int32_t i = 0; i < n; ++i)
+                if (sh[i].tiled) {
+                    Shape &p = alt[j++];
+                    sh[i].t_in = std::move(p.t_in);
+                    sh[i].t_end = std::move(p.t_end);
+                    sh[i].n_final = p.n_final;
+                    sh[i].halo_bytes = p.halo_bytes;
+                    sh[i].ck_mask = p.ck_mask;
+                    sh[i].ck_pitch = p.ck_pitch;
+                }
+        }
     }
 
     // ---- chunk-parallel backtrace (ka_parallel_bt.hpp) for the longest of the checkpointed results: it recomputes the
@@ -942,7 +990,10 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
         // two wavefronts per tile (ka_tiled2.hpp: one computes, one feeds) unless the engine was told otherwise
 #define KA_TP_LAUNCH(MM, PP, CC)                                                                                                                      \
     do {                                                                                                                                              \
-        if (e->tile_waves == 2)                                                                                                                       \
+        if (narrow)                                                                                                                                   \
+            hipLaunchKernelGGL((ka::forward_tn_kernel<MM, PP, CC>), dim3(grid), dim3(128), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo,  \
+                               d_prog, d_aux, d_ticket, verify, d_stats);                                                                             \
+        else if (e->tile_waves == 2)                                                                                                                       \
             hipLaunchKernelGGL((ka::forward_tp2_kernel<MM, PP, CC>), dim3(grid), dim3(128), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, \
                                d_prog, d_aux, d_ticket, verify, d_stats);                                                                             \
         else                                                                                                                                          \
@@ -1183,6 +1234,23 @@ int ka_debug_plan_tiles(int64_t T, int64_t S, int32_t V, int32_t beam_size, int3
     if (max_tiles < 0 || (max_tiles > 0 && (!t_in || !t_end)) || !shape_of(T, S, V, beam_size, max_move, sh))
         return fail(KA_ERR_BAD_ARGS, "ka_debug_plan_tiles: bad arguments");
     plan_tiles(sh, V, beam_size, max_move);
+    if (!sh.tileable) return 0;
+    for (size_t b = 0; b < sh.t_in.size() && b < (size_t)max_tiles; ++b) {
+        t_in[b] = sh.t_in[b];
+        t_end[b] = sh.t_end[b];
+    }
+    if (checkpoint_pitch) *checkpoint_pitch = (int64_t)sh.ck_pitch;
+    return (int)sh.t_in.size();
+}
+
+int ka_debug_plan_tiles_width(int64_t T, int64_t S, int32_t V, int32_t beam_size, int32_t max_move, int32_t positions, int32_t *t_in, int32_t *t_end,
+                              int32_t max_tiles, int64_t *checkpoint_pitch)
+{
+    Shape sh;
+    if (max_tiles < 0 || (max_tiles > 0 && (!t_in || !t_end)) || (positions != ka::kTnTile && positions != ka::kTpTile) ||
+        !shape_of(T, S, V, beam_size, max_move, sh))
+        return fail(KA_ERR_BAD_ARGS, "ka_debug_plan_tiles_width: bad arguments");
+    plan_tiles(sh, V, beam_size, max_move, positions);
     if (!sh.tileable) return 0;
     for (size_t b = 0; b < sh.t_in.size() && b < (size_t)max_tiles; ++b) {
         t_in[b] = sh.t_in[b];

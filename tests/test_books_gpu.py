@@ -17,7 +17,9 @@ from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 
-MODES = ["wave", "workgroup", "wave_exact", "tiled", "wave+parallel", "tiled+parallel", "auto"]
+# "tiled/256", "tiled/128": the tile pipeline with the tile width forced (ka_tiled2.hpp / ka_tiled_narrow.hpp; plain "tiled" lets the
+# library choose by the number of tiles alive at once)
+MODES = ["wave", "workgroup", "wave_exact", "tiled/256", "tiled/128", "wave+parallel", "tiled/256+parallel", "tiled/128+parallel", "auto"]
 _oracle_cache = {}
 
 
@@ -58,6 +60,8 @@ def _engine():
 def _set(eng, mode):
     """'form' or 'form+parallel' (chunk-parallel backtrace forced); 'auto' leaves both choices to the library"""
     form, _, bt = mode.partition("+")
+    form, _, width = form.partition("/")
+    eng.set_tile_width(int(width or 0))
     eng.set_mode(form)
     eng.set_backtrace(bt or ("auto" if form == "auto" else "serial"))
 
@@ -154,7 +158,7 @@ def test_full_lattice_mode_vs_oracle_reduced_size(T, S, V):
             want = O.ctc_best_path_c(lp, lab, beam, 4, return_total=True)
         except ValueError:
             want = None
-        for mode in ("auto", "tiled+parallel", "tiled"):
+        for mode in ("auto", "tiled/128+parallel", "tiled/256", "tiled/128"):
             _set(eng, mode)
             try:
                 b = DeviceBatch(lps, labs, beam)
@@ -258,14 +262,15 @@ def test_wide_band_with_neg_inf_log_probs_is_answered(beam):
             p, l, s = ka.ctc_best_path(host[1][0], host[1][1], beam_size=bm, verbose=False)
             assert np.array_equal(p, want[1][0]) and np.array_equal(l, want[1][1]) and np.array_equal(s.view(np.int32), want[1][2].view(np.int32))
         # the explicit tiled form has no answer for the wide ones with -inf and says so
-        _set(eng, "tiled")
-        b = DeviceBatch(lps, labs, bm)
-        st = b.run(raise_on_error=False)
-        assert st[0] == 0 and st[1] == -7 and st[3] == -7, st
-        _compare(b, 0, want[0], "tiled, finite lattice")
-        if want[2] is not None:
-            assert st[2] == 0
-            _compare(b, 2, want[2], "tiled, narrow lattice redone exactly")
+        for mode in ("tiled/256", "tiled/128"):
+            _set(eng, mode)
+            b = DeviceBatch(lps, labs, bm)
+            st = b.run(raise_on_error=False)
+            assert st[0] == 0 and st[1] == -7 and st[3] == -7, (mode, st)
+            _compare(b, 0, want[0], f"{mode}, finite lattice")
+            if want[2] is not None:
+                assert st[2] == 0
+                _compare(b, 2, want[2], f"{mode}, narrow lattice redone exactly")
     finally:
         _set(eng, "auto")
 
@@ -283,7 +288,7 @@ def test_cfg2_whole_lattice_50k_frames_vs_oracle():
     want = O.ctc_best_path_c(O.hash_logprobs_c(T, V, 0), O.hash_labels(S, V, 0), 2 * L + 2, 4, return_total=True)
     eng = _engine()
     try:
-        for mode in ("auto", "tiled"):
+        for mode in ("auto", "tiled/256", "tiled/128"):
             _set(eng, mode)
             b = DeviceBatch(lps, labs, 2 * L + 2)
             b.run()
@@ -302,12 +307,12 @@ def test_meian_book_with_the_hand_off_self_check_on(books_on_device):
     want = _oracle("meian")
     eng = _engine()
     try:
-        for flags in (1, 3):
-            _set(eng, "tiled")
+        for mode, flags in (("tiled/256", 1), ("tiled/256", 3), ("tiled/128", 1), ("tiled/128", 3)):
+            _set(eng, mode)
             eng.set_verify(flags)
             b = DeviceBatch(lps, labs)
             st = b.run(raise_on_error=False)
-            assert not (st != 0).any(), (flags, sorted(set(st[st != 0].tolist())))
+            assert not (st != 0).any(), (mode, flags, sorted(set(st[st != 0].tolist())))
             _check_against_oracle(b, want)
     finally:
         eng.set_verify(0)

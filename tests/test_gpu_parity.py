@@ -13,22 +13,25 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["wave", "workgroup", "wave_exact", "tiled", "wave+parallel", "tiled+parallel"])
+@pytest.fixture(scope="module", params=["wave", "workgroup", "wave_exact", "tiled/256", "tiled/128", "wave+parallel", "tiled/256+parallel", "tiled/128+parallel"])
 def ka(request):
     """Every test runs in every kernel form: one wavefront per lattice checkpointed / exact,
-    four wavefronts per lattice, the tile pipeline - and the two checkpointed forms once more with the chunk-parallel
-    backtrace forced (the default picks it by batch size).  Results must be identical."""
+    four wavefronts per lattice, the tile pipeline with tiles of 256 and of 128 positions - and the checkpointed forms once
+    more with the chunk-parallel backtrace forced (the default picks it by batch size).  Results must be identical."""
     import torch
     assert torch.cuda.is_available()
     import kokoro_align_amd as ka
     from kokoro_align_amd import _lib
     assert os.path.exists(ka.library_path()), "HIP library not built"
     mode, _, bt = request.param.partition("+")
+    mode, _, width = mode.partition("/")
     eng = _lib.default_engine(torch.cuda.current_device())
     eng.set_mode(mode)
+    eng.set_tile_width(int(width or 0))
     eng.set_backtrace(bt or "serial")
     yield ka
     eng.set_mode("auto")
+    eng.set_tile_width(0)
     eng.set_backtrace("auto")
 
 

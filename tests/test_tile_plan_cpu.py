@@ -9,16 +9,19 @@ import ctypes
 import numpy as np
 import pytest
 
-TILE = 256
+WIDTHS = [256, 128]       # positions per tile: ka_tiled.hpp / ka_tiled2.hpp, ka_tiled_narrow.hpp
 
 
-def _plan(T, S, V, beam, max_move=4, cap=4096):
+def _plan(T, S, V, beam, max_move=4, cap=4096, width=256):
     from kokoro_align_amd import _lib
     L = _lib.load_library()
     t_in = np.zeros(cap, np.int32)
     t_end = np.zeros(cap, np.int32)
     pitch = ctypes.c_int64(0)
-    n = L.ka_debug_plan_tiles(T, S, V, beam, max_move, t_in.ctypes.data, t_end.ctypes.data, cap, ctypes.byref(pitch))
+    if width == 256:
+        n = L.ka_debug_plan_tiles(T, S, V, beam, max_move, t_in.ctypes.data, t_end.ctypes.data, cap, ctypes.byref(pitch))
+    else:
+        n = L.ka_debug_plan_tiles_width(T, S, V, beam, max_move, width, t_in.ctypes.data, t_end.ctypes.data, cap, ctypes.byref(pitch))
     return n, t_in[:max(n, 0)], t_end[:max(n, 0)], pitch.value
 
 
@@ -45,12 +48,13 @@ SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("TILE", WIDTHS)
 @pytest.mark.parametrize("T,S,V,beam", SHAPES)
-def test_tile_plan_matches_the_band_frame_by_frame(T, S, V, beam):
-    n, t_in, t_end, pitch = _plan(T, S, V, beam)
+def test_tile_plan_matches_the_band_frame_by_frame(T, S, V, beam, TILE):
+    n, t_in, t_end, pitch = _plan(T, S, V, beam, width=TILE)
     L, lo, hi = _band(T, S, beam)
     assert n > 0, "shape should be tileable"
-    # which tiles does the band ever touch, and in which frames?  tile b is touched in frame t iff lo(t) < 256(b+1) and hi(t) > 256 b
+    # which tiles does the band ever touch, and in which frames?  tile b is touched in frame t iff lo(t) < TILE (b+1) and hi(t) > TILE b
     n_tiles = (L + TILE - 1) // TILE
     want_in, want_end = [], []
     for b in range(n_tiles):
@@ -69,15 +73,19 @@ def test_tile_plan_matches_the_band_frame_by_frame(T, S, V, beam):
     # checkpoint row: wide enough that the positions alive at once never alias
     span = max(int(hi[t]) - (int(lo[t]) // TILE) * TILE for t in range(0, T, max(1, T // 500)))
     assert pitch // 4 >= min(span, n_tiles * TILE)
+    assert pitch // 4 % 256 == 0      # (whatever the tile width: the readers of the checkpoints work in windows of 256 positions)
 
 
 def test_shapes_outside_the_tiled_form_are_reported():
+    from kokoro_align_amd import _lib
+    assert _lib.load_library().ka_debug_plan_tiles_width(1000, 100, 39, 1000, 4, 64, None, None, 0, None) < 0   # widths are 128 and 256
     assert _plan(1000, 100, 65, 1000)[0] == 0          # V > 64
     assert _plan(1000, 100, 39, 1000, max_move=5)[0] == 0
     assert _plan(0, 100, 39, 1000)[0] < 0              # bad arguments: a status, not a crash
 
 
-def test_random_shapes():
+@pytest.mark.parametrize("TILE", WIDTHS)
+def test_random_shapes(TILE):
     rng = np.random.default_rng(7)
     for _ in range(40):
         T = int(rng.integers(40, 6000))
@@ -85,7 +93,7 @@ def test_random_shapes():
         beam = int(rng.choice([16, 100, 500, 1000, 1009, 1010, 3000, 2 * (2 * S + 1) + 3]))
         if (2 * S + 1) / T > 200:
             continue
-        n, t_in, t_end, _ = _plan(T, S, 39, beam)
+        n, t_in, t_end, _ = _plan(T, S, 39, beam, width=TILE)
         L, lo, hi = _band(T, S, beam)
         if n == 0:
             continue   # (the band jumps over a whole tile in one frame: not planned)

@@ -21,6 +21,7 @@ from kokoro_align_amd.align import DeviceBatch
 def timed(lps, labs, mode, beam=1000, reps=3):
     b = DeviceBatch(lps, labs, beam)
     b.engine.set_mode(mode)
+    b.engine.set_tile_width(int(os.environ.get("KA_TILE_WIDTH", "0")))
     b.engine.set_profiling(True)
     b.run()
     t0 = time.perf_counter()
@@ -29,6 +30,7 @@ def timed(lps, labs, mode, beam=1000, reps=3):
     dt = (time.perf_counter() - t0) / reps
     k = b.engine.last_kernel_ms()
     b.engine.set_mode("auto")
+    b.engine.set_tile_width(0)
     return b, {"ms": dt * 1e3, "forward_ms": k["forward"], "backtrace_ms": k["backtrace"], "gather_ms": k["gather"]}
 
 

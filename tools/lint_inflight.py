@@ -14,6 +14,10 @@ reports every v_mov / DPP mov whose SOURCE is a register written by an inline-as
 have landed.  Program order is not execution order across branches, so this is a lint, not a proof: it is
 exact for the straight-line unrolled frame code and for the copies a compiler puts in front of a back-edge.
 
+The same for LDS: the tile kernels' frame loops read LDS from inline asm (ds_read) and wait with counted lgkmcnt (LDS
+instructions complete in order; scalar loads share the counter, which only makes a wait stricter).  ANY instruction that
+reads a register such a read may still be writing is reported.
+
 A third check: an SGPR written by v_readfirstlane / v_readlane and read by a vector-memory instruction less than five
 wait states later (hipcc pads its own code, not asm statements).
 
@@ -29,7 +33,7 @@ import os
 import re
 import sys
 
-KERNELS = ("forward_ck", "forward_w16", "forward_wg4", "backtrace_rc", "backtrace_w16", "forward_tp", "chunk_map")
+KERNELS = ("forward_ck", "forward_w16", "forward_wg4", "backtrace_rc", "backtrace_w16", "forward_tp", "forward_tn", "chunk_map")
 VMEM = re.compile(r"\s*(global_load|global_store|buffer_load|buffer_store|flat_load|flat_store|global_atomic)\w*\s+(.*)")
 WAIT = re.compile(r"\s*s_waitcnt\s+(.*)")
 MOV = re.compile(r"\s*v_mov_b32(?:_e32|_dpp|_e64)?\s+(v[0-9]+),\s*(v[0-9]+)\b")
@@ -55,6 +59,7 @@ def check(path):
         pending = {}               # register -> issue index of the inline-asm load that writes it
         in_asm = False
         found = []
+        lds_issued, lds_pending = 0, {}
         for ln in k.split("\n"):
             if "ASMSTART" in ln:
                 in_asm = True
@@ -62,6 +67,43 @@ def check(path):
             if "ASMEND" in ln:
                 in_asm = False
                 continue
+            md = re.match(r"\s*(ds_\w+)\s+(.*)", ln)
+            if md:
+                lds_issued += 1
+                ops = [o.strip() for o in re.split(r",\s*", md.group(2).split(" offset")[0])]
+                is_read = md.group(1).startswith(("ds_read", "ds_bpermute", "ds_permute", "ds_swizzle", "ds_consume", "ds_append"))
+                for o in (ops[1:] if is_read else ops):
+                    for r in regs(o):
+                        if r in lds_pending:
+                            found.append("LDS read in flight: " + ln.strip())
+                if is_read:
+                    for r in regs(ops[0]):
+                        if in_asm and md.group(1).startswith("ds_read"):
+                            lds_pending[r] = lds_issued
+                        else:
+                            lds_pending.pop(r, None)
+                continue
+            if lds_pending:
+                mwl = WAIT.match(ln)
+                if mwl:
+                    ml = re.search(r"lgkmcnt\((\d+)\)", mwl.group(1))
+                    if ml:
+                        landed = lds_issued - int(ml.group(1))
+                        for r in [r for r, i in lds_pending.items() if i <= landed]:
+                            del lds_pending[r]
+                elif re.match(r"\s*(v_|global_|buffer_|flat_)\w+\s", ln):
+                    body = ln.split(";")[0]
+                    parts = body.split(None, 1)
+                    ops = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
+                    is_store = parts[0].startswith(("global_store", "buffer_store", "flat_store"))
+                    for o in (ops if is_store else ops[1:]):
+                        for r in regs(o.split()[0] if o else o):
+                            if r in lds_pending:
+                                found.append("LDS read in flight: " + ln.strip())
+                    if not is_store and ops and not parts[0].startswith("v_cmp"):
+                        for r in regs(ops[0]):
+                            if r in lds_pending:
+                                found.append("LDS read in flight (overwritten): " + ln.strip())
             mv = VMEM.match(ln)
             if mv:
                 issued += 1

@@ -12,6 +12,7 @@ T, S, V, beam = (int(x) for x in sys.argv[1:5]) if len(sys.argv) >= 5 else (5000
 lps, labs = W.device_book([(T, S)], V=V, seed0=0)
 b = DeviceBatch(lps, labs, beam)
 b.engine.set_mode("tiled")
+b.engine.set_tile_width(int(os.environ.get("KA_TILE_WIDTH", "0")))
 b.engine.set_profiling(True)
 b.engine.set_verify(4)
 b.run(); b.run()
@@ -35,4 +36,5 @@ simd = collections.Counter(((int(r[6]) >> 48) & 0xf, (int(r[6]) >> 45) & 7, (int
 cu = collections.Counter(k[:3] for k in simd.elements())
 print("tiles per SIMD (max):", max(simd.values()), " tiles per CU (max):", max(cu.values()), " distinct CUs:", len(cu))
 b.engine.set_mode("auto")
+b.engine.set_tile_width(0)
 b.engine.set_verify(0)

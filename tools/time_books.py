@@ -19,6 +19,7 @@ for name, shapes, seed0 in cases:
     b.engine.set_mode(mode)
     b.engine.set_backtrace(bt)
     b.engine.set_tile_lds(lds)
+    b.engine.set_tile_width(int(os.environ.get("KA_TILE_WIDTH", "0")))
     b.engine.set_profiling(True)
     b.run()
     rows = []
@@ -29,6 +30,6 @@ for name, shapes, seed0 in cases:
     ok = all(int(p[-1]) == 2 * s for p, (_, s) in zip(b.path, shapes))
     print(json.dumps({"case": name, "mode": mode, "backtrace": bt, "tile_lds": lds, "lattices": len(shapes), "frames": sum(t for t, _ in shapes),
                       "longest": max(t for t, _ in shapes), "forward_ms": best["forward"], "backtrace_ms": best["backtrace"], "ends_ok": ok}), flush=True)
-    b.engine.set_mode("auto"); b.engine.set_backtrace("auto"); b.engine.set_profiling(False); b.engine.set_tile_lds(0)
+    b.engine.set_tile_width(0); b.engine.set_mode("auto"); b.engine.set_backtrace("auto"); b.engine.set_profiling(False); b.engine.set_tile_lds(0)
     del b, lps, labs
     torch.cuda.empty_cache()
