@@ -172,6 +172,10 @@ int ka_debug_set_tile_lds(ka_engine *e, int32_t bytes);
  * the tiles; only with two wavefronts per tile), or 0 = the library's choice (128 when all the launch's tiles are alive on
  * no more than half the device's SIMDs).  Results are identical. */
 int ka_debug_set_tile_width(ka_engine *e, int32_t positions);
+/* 128-position tiles: 1 = the feeder wavefront looks up the emissions of a block and folds the band's kills into them (48-56 KB
+ * of LDS per tile instead of 40: two or three tiles per CU), 0 = the compute wavefront reads the staged rows itself, -1 = the
+ * library's choice.  Results are identical. */
+int ka_debug_set_tile_gather(ka_engine *e, int32_t how);
 /* The serial backtrace's output form: 1 = labels and scores gathered from memory after the walk (fewer vector instructions:
  * launches that fill the chip; by the counters 17 % more HBM traffic per step), 0 or -1 (default) = collected by the walk in
  * registers.  Results are identical. */

@@ -191,6 +191,7 @@ struct ka_engine {
     int32_t verify = 0;                    // ka_engine_set_verify: self-checks of the tiled form's hand-off
     int32_t tile_waves = 2;                // ka_engine_set_tile_waves: wavefronts per tile of the tiled form
     int32_t rc_gather = -1;                // ka_debug_set_rc_gather: -1 the library's rule, 0 / 1 the serial backtrace's output form
+    int32_t tile_gather = -1;              // ka_debug_set_tile_gather: the 128-position tiles' feeder looks up the emissions (1), does not (0), -1 = the engine chooses
     int32_t tile_width = 0;                // ka_debug_set_tile_width: 0 = the engine chooses, 128 or 256
     int32_t tile_lds = 0;                  // ka_debug_set_split's third knob: LDS bytes a tile workgroup requests (0: kTpLdsRequest)
     int32_t split_tiled = -1, split_par = -1;   // ka_debug_set_split: how many of the longest lattices run tiled / are walked back chunk-parallel (-1: cost model)
@@ -483,6 +484,14 @@ int ka_debug_set_tile_width(ka_engine *e, int32_t positions)
     return KA_OK;
 }
 
+int ka_debug_set_tile_gather(ka_engine *e, int32_t how)
+{
+    if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
+    if (how < -1 || how > 1) return fail(KA_ERR_BAD_ARGS, "ka_debug_set_tile_gather: -1, 0 or 1");
+    e->tile_gather = how;
+    return KA_OK;
+}
+
 int ka_engine_set_tile_waves(ka_engine *e, int32_t waves)
 {
     if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
@@ -662,10 +671,11 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
         }
         for (int32_t i = 0; i < n; ++i) n_tiled += sh[i].tiled ? 1 : 0;
     }
-    // ---- tile width: 128 positions (two cells per lane, ka_tiled_narrow.hpp: a shorter frame, twice the tiles and twice the
-    // hand-offs) while the tiles alive at once are no more than 2.5 per SIMD, else 256.  Measured on prefixes of the corpus
-    // stand-in, all tiled (tools/sweep_width.py, profiles/r03_sweep_width.jsonl): 128 positions are 10-15 % faster up to 200
-    // chapters (~1800 tiles alive), even at 250 (~2250), 4 % slower at 320 (~2900), 15 % slower for all 462.
+    // ---- tile width: 128 positions (two cells per lane and three wavefronts per tile, ka_tiled_narrow.hpp: a frame of half the
+    // instructions, twice the tiles and twice the hand-offs, 48-56 KB of LDS per tile) while the tiles alive at once are no
+    // more than 2.6 per workgroup slot of the device, else 256.  Measured on prefixes of the corpus stand-in, all tiled, V = 39:
+    // three workgroups per CU (tools/sweep_width.py, profiles/r03_sweep_width.jsonl): against 256 positions the forward kernel
+    // takes 0.66 x the time for one chapter, 0.71 x for 64 (~580 tiles alive), 0.77 x for 120, 0.93 x for 200 (~1800), 1.17 x for 320 (~2900).
     bool narrow = false;
     if (n_tiled > 0 && e->tile_waves == 2 && e->tile_width != ka::kTpTile) {
         std::vector<Shape> alt;
@@ -679,7 +689,8 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
             alive_now += std::min<int64_t>((int64_t)p.t_in.size(), (p.W + 2 * ka::kTnTile - 1) / ka::kTnTile);
             alt.push_back(std::move(p));
         }
-        if (ok && (e->tile_width == ka::kTnTile || 2 * alive_now <= 5 * (int64_t)e->n_simd)) {
+        const int64_t slots = (int64_t)(e->n_simd / 4) * ((V == 39 && max_move == 4) ? 3 : 2);   // (V = 39: 47.5 KB per workgroup, else 55.5)
+        if (ok && (e->tile_width == ka::kTnTile || 5 * alive_now <= 13 * slots)) {
             narrow = true;
             size_t j = 0;
             for (int32_t i = 0; i < n; ++i)
@@ -962,6 +973,7 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
         const unsigned lds = e->tile_lds ? (unsigned)e->tile_lds : ((int64_t)n_tasks <= (int64_t)e->n_simd / 2 && e->tile_waves == 2 ? 2u * ka::kTpLdsRequest : ka::kTpLdsRequest);
         // ka_engine_set_verify(1) (tests): every halo slot starts as a NaN pattern and a tile that consumes one reports KA_ERR_INTERNAL
         const int verify = e->verify;
+        const bool gather = narrow && e->tile_gather != 0;
         if (verify & 1) {
             size_t lo_b = ~size_t(0), hi_b = 0;
             for (int32_t i = 0; i < n; ++i)
@@ -990,9 +1002,13 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
         // two wavefronts per tile (ka_tiled2.hpp: one computes, one feeds) unless the engine was told otherwise
 #define KA_TP_LAUNCH(MM, PP, CC)                                                                                                                      \
     do {                                                                                                                                              \
-        if (narrow)                                                                                                                                   \
-            hipLaunchKernelGGL((ka::forward_tn_kernel<MM, PP, CC>), dim3(grid), dim3(128), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo,  \
-                               d_prog, d_aux, d_ticket, verify, d_stats);                                                                             \
+        if (narrow && gather) {                                                                                                                       \
+            const unsigned need = (unsigned)ka::TnLds<PP, CC, true>::kTotal;                                                                          \
+            hipLaunchKernelGGL((ka::forward_tn_kernel<MM, PP, CC, true>), dim3(grid), dim3(192), std::max(need, (unsigned)e->tile_lds), stream, d_lats, \
+                               d_tasks, (int)n_tasks, d_meta, d_halo, d_prog, d_aux, d_ticket, verify, d_stats);                                      \
+        } else if (narrow)                                                                                                                            \
+            hipLaunchKernelGGL((ka::forward_tn_kernel<MM, PP, CC, false>), dim3(grid), dim3(128), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta,  \
+                               d_halo, d_prog, d_aux, d_ticket, verify, d_stats);                                                                     \
         else if (e->tile_waves == 2)                                                                                                                       \
             hipLaunchKernelGGL((ka::forward_tp2_kernel<MM, PP, CC>), dim3(grid), dim3(128), lds, stream, d_lats, d_tasks, (int)n_tasks, d_meta, d_halo, \
                                d_prog, d_aux, d_ticket, verify, d_stats);                                                                             \

@@ -189,6 +189,86 @@ __device__ __forceinline__ void tn_block_frames(TnTile<M, ZL> &c, uint32_t tb, f
     tn_frame<M, ZL, PITCH, GUARDED, F>(c, tb + F, H, in, A, NINF);
     if constexpr (F + 1 < kTpBlock) tn_block_frames<M, ZL, PITCH, GUARDED, F + 1>(c, tb, H, in, A, NINF);
 }
+// ---------------------------------------------------------------------------------------
+// GATHER form: the FEEDER also looks up the emissions.  For every frame of block it+1 it reads the blank's and the lane's
+// label's log-prob from the staged rows and leaves them as a pair {blank, label} per lane in LDS - with -inf in place of
+// the emission of every cell the band code would kill after that frame (a sum with -inf IS the kill: rule i / rule ii of
+// tp_frame become writes of single words, worked out for the 32 frames of the block at once, lane = frame).  The compute
+// wavefront's frame is then: wait, staging write, 7 vector instructions, ONE 8-byte read (which is the second operand of
+// the v_pk_add_f32 as it lands) and the packet read - 11 instructions instead of 14, no band code, no branch.  Its reads do
+// not cross into the next block (whose pairs the feeder is writing during this iteration): four frames are primed at the
+// start of a block, the last four frames read nothing, and the hand-written waits count accordingly.
+// LDS: 2 x 16 KB of pairs; the compute wavefront no longer reads rows, so two row slots do (the block being looked up and
+// the one landing) - 47.5 KB per workgroup for V = 39 (three per CU), 55.5 KB for V = 64 (two).
+// ---------------------------------------------------------------------------------------
+constexpr int kTgPairBytes = kTpBlock * 64 * 8;
+template <int PITCH, bool CONTIG, bool GATHER>
+struct TnLds {
+    static constexpr int kRowDmas = !CONTIG ? kTpBlock : (kTpBlock * PITCH + 1023) / 1024;
+    static constexpr int kRing = GATHER ? 2 : kTpRing;                                        // row slots
+    static constexpr int kSlot = GATHER && CONTIG ? kRowDmas * 1024 : kTpSlotBytes;           // bytes per row slot
+    static constexpr int kHalo = kRing * kSlot;                                               // packets of the tile below: kTpRing slots of 32
+    static constexpr int kPoll = kHalo + kTpRing * kTpBlock * 16;
+    static constexpr int kStage = kPoll + 16;
+    static constexpr int kStat = kStage + kTp2StageBytes;                                     // 12 diagnostic words, the ticket at +48
+    static constexpr int kBand = kStat + 64;                                                  // !GATHER: two band buffers;  GATHER: two pair buffers
+    static constexpr int kTotal = kBand + (GATHER ? 2 * kTgPairBytes : 2 * kTp2BandBytes);
+};
+static_assert(TnLds<256, true, false>::kTotal <= (int)kTpLdsRequest, "LDS budget of the narrow tile");
+
+struct TgIn {
+    f32x2 e;      // {blank emission, label emission} of the lane's two cells, -inf where the cell dies after the frame
+    f32x4 hp;     // packet of the tile below
+};
+template <int G>
+__device__ __forceinline__ void tg_read(TgIn &in, uint32_t pairs, uint32_t packets)
+{
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(in.e) : "v"(pairs), "n"(G * 512));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(in.hp) : "v"(packets), "n"(G * 16));
+}
+template <int N>
+__device__ __forceinline__ void tg_wait(TgIn &in)
+{
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(in.e), "+v"(in.hp) : "n"(N));
+}
+__device__ __forceinline__ void tg_wait_all(TgIn (&in)[4])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(in[0].e), "+v"(in[0].hp), "+v"(in[1].e), "+v"(in[1].hp), "+v"(in[2].e), "+v"(in[2].hp), "+v"(in[3].e), "+v"(in[3].hp));
+}
+// LDS instructions frame F of a block issues: the staging write, and the two reads of frame F+4 while that is in the block
+constexpr int tg_ops(int F) { return 1 + (F + 4 < kTpBlock ? 2 : 0); }
+template <int M, bool ZL, bool GUARDED, int F>
+__device__ __forceinline__ void tg_frame(TnTile<M, ZL> &c, uint32_t t, float (&H)[3], TgIn (&in)[4], uint32_t pairs, uint32_t packets, float NINF)
+{
+    const bool live = !GUARDED || ((int32_t)t >= c.t_in && (int32_t)t < c.t_end);
+    if (live) {
+        const float b = c.S[0], l = c.S[1];
+        const float ml = cell_label_max<M, ZL>(l, b, H[0], H[1], c.vz0);
+        const float mb = cell_blank_max<M>(b, H[0], H[2]);
+        c.S = f32x2{mb, ml} + in[0].e;
+    }
+    if constexpr (F + 1 < kTpBlock) {
+        // frame F+1's pair and packet: primed (F + 1 < 4), else read in frame F-3 - the instructions of frames F-2 and F-1 may
+        // still be in flight
+        if constexpr (F >= 3) tg_wait<tg_ops(F - 2) + tg_ops(F - 1)>(in[1]);
+        H[0] = wave_shr1(in[1].hp[3], c.S[1]);
+        H[1] = wave_shr1(in[1].hp[2], c.S[0]);
+        H[2] = wave_shr1(in[1].hp[1], H[0]);
+    }
+    asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(c.lds_stage), "v"(c.S), "n"(F * 16) : "memory");
+    in[0] = in[1];
+    in[1] = in[2];
+    in[2] = in[3];
+    if constexpr (F + 4 < kTpBlock) tg_read<F + 4>(in[3], pairs, packets);
+    else asm volatile("" : "=v"(in[3].e), "=v"(in[3].hp));   // (nothing to read: a fresh value, so that in[2] and in[3] are not one register the next wait "modifies")
+}
+template <int M, bool ZL, bool GUARDED, int F>
+__device__ __forceinline__ void tg_block_frames(TnTile<M, ZL> &c, uint32_t tb, float (&H)[3], TgIn (&in)[4], uint32_t pairs, uint32_t packets, float NINF)
+{
+    tg_frame<M, ZL, GUARDED, F>(c, tb + F, H, in, pairs, packets, NINF);
+    if constexpr (F + 1 < kTpBlock) tg_block_frames<M, ZL, GUARDED, F + 1>(c, tb, H, in, pairs, packets, NINF);
+}
+
 template <int M, bool ZL>
 __device__ __forceinline__ void tn_publish_block(TnTile<M, ZL> &c, uint32_t tb, int lane)
 {
@@ -205,17 +285,24 @@ __device__ __forceinline__ void tn_checkpoint(TnTile<M, ZL> &c, uint32_t t_next 
     asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2\n\ts_nop 1" : : "v"(c.ck_off), "v"(c.S), "s"(c.ck + ((size_t)(t_next / kCkFrames) - 1) * (size_t)c.ck_pitch) : "memory");
 }
 
-template <int M, bool ZL, int PITCH, bool CONTIG>
+template <int M, bool ZL, int PITCH, bool CONTIG, bool GATHER>
 __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk, int32_t *meta, char *halo, gu32w_t prog, TileAux *aux,
                                              uint32_t lds_rows, uint32_t lds_halo, int verify, TpStats *stats_out)
 {
     typedef __attribute__((address_space(3))) uint32_t *lu32_t;
     const int lane = threadIdx.x & 63;
-    const bool feeder = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0;
-    const uint32_t lds_poll = lds_halo + kTpRing * kTpBlock * 16;
-    const uint32_t lds_stage0 = lds_poll + 16;                                  // two staging buffers of kTpStageBytes
-    const uint32_t stat_lds = lds_stage0 + kTp2StageBytes;                      // diagnostic words, then two flag words
-    const uint32_t lds_band = stat_lds + 64;                                    // two buffers of kTp2BandBytes: the band code's kill words and event mask of a block
+    // wavefront 0 computes, wavefront 1 feeds (memory: polls, requests, publishes), and in the GATHER form wavefront 2 does the
+    // feeder's LDS work (finiteness sum, emission look-up, band): with the look-up the feeder alone took 5100 cycles per
+    // block against the compute wavefront's 2500
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool feeder = role == 1, looker = GATHER && role == 2;
+    typedef TnLds<PITCH, CONTIG, GATHER> Lds;
+    constexpr int kRowRing = Lds::kRing, kRowSlot = Lds::kSlot;
+    const uint32_t lds_poll = lds_rows + Lds::kPoll;
+    const uint32_t lds_stage0 = lds_rows + Lds::kStage;                         // two staging buffers of kTpStageBytes
+    const uint32_t stat_lds = lds_rows + Lds::kStat;                            // diagnostic words, then two flag words
+    const uint32_t lds_band = lds_rows + Lds::kBand;                            // two buffers of kTp2BandBytes: the band code's kill words and event mask of a block
+    const uint32_t lds_pairs = lds_band;                                        // GATHER: two buffers of kTgPairBytes instead
     if (threadIdx.x < 10) ((lu32_t)(uintptr_t)stat_lds)[threadIdx.x] = 0;
     unsigned long long ph = 0;
     auto phase = [&](int w) {
@@ -225,7 +312,7 @@ __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk
             ph = now;
         }
     };
-    if ((verify & 4) && !feeder && lane == 0) {   // where the compute wavefront runs (the feeder reports its own place below)
+    if ((verify & 4) && role == 0 && lane == 0) {   // where the compute wavefront runs (the feeder reports its own place below)
         uint32_t hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         ((lu32_t)(uintptr_t)stat_lds)[10] = hw & 0xffffu;
@@ -288,12 +375,13 @@ __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk
     typedef __attribute__((address_space(3))) char *lchar_t;
     const uint32_t last_row = c.T - 1;
     const uint32_t last_slot = (uint32_t)c.t_end - 1;     // this tile reads slots t_in .. t_end - 1
-    auto ring = [](int32_t k) { return (uint32_t)((k % kTpRing + kTpRing) % kTpRing); };
-    constexpr int kRowDmas = !CONTIG ? kTpBlock : (kTpBlock * PITCH + 1023) / 1024;   // LDS-DMA instructions per block of rows
+    auto ring = [](int32_t k) { return (uint32_t)((k % kTpRing + kTpRing) % kTpRing); };            // packets and poll words
+    auto rslot = [](int32_t k) { return (uint32_t)((k % kRowRing + kRowRing) % kRowRing); };        // rows
+    constexpr int kRowDmas = Lds::kRowDmas;   // LDS-DMA instructions per block of rows
     static_assert(CONTIG || PITCH == kTpRowBytes, "row-by-row staging uses 256-byte rows");
     auto issue_block = [&](int32_t k) {    // k >= 0
         const uint32_t tb = (uint32_t)k * kTpBlock, slot = ring(k);
-        lchar_t dst = (lchar_t)(uintptr_t)(c.lds_rows + slot * kTpSlotBytes);
+        lchar_t dst = (lchar_t)(uintptr_t)(c.lds_rows + rslot(k) * kRowSlot);
         if constexpr (!CONTIG) {
             const char *rp = c.lp + (size_t)(tb < last_row ? tb : last_row) * c.ld;
             if (tb + kTpBlock <= c.T) {
@@ -331,7 +419,7 @@ __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk
     bool stale = false;
     auto landed_block = [&](int32_t k) {
         const uint32_t slot = ring(k);
-        const uint32_t r = c.lds_rows + slot * kTpSlotBytes + (uint32_t)lane * 16u;
+        const uint32_t r = c.lds_rows + rslot(k) * kRowSlot + (uint32_t)lane * 16u;
         constexpr int kReads = !CONTIG ? kTpSlotBytes / 1024 : kRowDmas;
         f32x4 v[kReads];
 #pragma unroll
@@ -354,6 +442,45 @@ __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk
     };
 
     const int32_t kb0 = c.t_in / kTpBlock, kb1 = (c.t_end - 1) / kTpBlock;   // first and last block
+    auto lds_work = [&](int32_t it, uint32_t tb) {
+        // block it+1 landed before the last barrier: its finiteness sum
+        if (it + 1 >= kb0 && it + 1 <= kb1) landed_block(it + 1);
+        // the band bookkeeping of the NEXT block (which positions of the tile enter or leave the band in which frame), for
+        // the compute wavefront to pick up after the next barrier: ~60 instructions it does not have to issue
+        if (it + 1 >= kb0 && it + 1 <= kb1) {
+            tn_band_block(c, tb + kTpBlock, lane);
+            if constexpr (!GATHER) {
+                const uint32_t bb = lds_band + (uint32_t)((it + 1) & 1) * kTp2BandBytes;
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                *(__attribute__((address_space(3))) u32x2 *)(uintptr_t)(bb + (uint32_t)lane * 8u) = u32x2{c.KL, c.KE};
+                if (lane == 0) *(lu32_t)(uintptr_t)(bb + 512u) = c.ev;
+            } else {
+                // the emissions of block it+1, per frame and lane {blank, label} ...
+                const uint32_t rows = c.lds_rows + rslot(it + 1) * kRowSlot;
+                const uint32_t pb = lds_pairs + (uint32_t)((it + 1) & 1) * kTgPairBytes;
+                const uint32_t mine = pb + (uint32_t)lane * 8u, col = rows + (uint32_t)c.la0;
+#pragma unroll
+                for (int g = 0; g < kTpBlock; g += 8) {      // (eight frames' reads in flight at a time: one by one the loop ran at the LDS latency)
+                    f32x2 e[8];
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) e[f] = f32x2{lds_f32(rows + (g + f) * PITCH), lds_f32(col + (g + f) * PITCH)};
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) *(__attribute__((address_space(3))) f32x2 *)(uintptr_t)(mine + (g + f) * 512) = e[f];
+                }
+                // ... and -inf over those of the cells that die after a frame: lane f < 32 deals with frame f - the positions
+                // that left the band before it (rule ii: its own KL) and those that enter after it (rule i: KE of lane f+1);
+                // position r of the tile is word r of the frame's 512 bytes
+                const uint32_t ke = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c.KE, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+                uint32_t r2 = c.KL & 0xffffu, n2 = lane < kTpBlock ? c.KL >> 16 : 0u, r1 = ke & 0xffffu, n1 = lane < kTpBlock ? ke >> 16 : 0u;
+                const uint32_t fb = pb + (uint32_t)lane * 512u;
+                while (__builtin_amdgcn_ballot_w64((n2 | n1) != 0u)) {
+                    if (n2) { *(__attribute__((address_space(3))) float *)(uintptr_t)(fb + r2 * 4u) = NINF; ++r2; --n2; }
+                    if (n1) { *(__attribute__((address_space(3))) float *)(uintptr_t)(fb + r1 * 4u) = NINF; ++r1; --n1; }
+                }
+            }
+            tn_band_advance(c);
+        }
+    };
     bool fed = true;
     const TnIn none = {0.0f, 0.0f, f32x4{NINF, NINF, NINF, NINF}};
     TnIn in[4] = {none, none, none, none};
@@ -397,27 +524,51 @@ __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk
                 if (request) issue_block(it + 2);
             }
             phase(6);
-            // block it+1 landed before the last barrier: its finiteness sum
-            if (it + 1 >= kb0 && it + 1 <= kb1) landed_block(it + 1);
-            // the band bookkeeping of the NEXT block (which positions of the tile enter or leave the band in which frame), for
-            // the compute wavefront to pick up after the next barrier: ~60 instructions it does not have to issue
-            if (it + 1 >= kb0 && it + 1 <= kb1) {
-                tn_band_block(c, tb + kTpBlock, lane);
-                const uint32_t bb = lds_band + (uint32_t)((it + 1) & 1) * kTp2BandBytes;
-                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                *(__attribute__((address_space(3))) u32x2 *)(uintptr_t)(bb + (uint32_t)lane * 8u) = u32x2{c.KL, c.KE};
-                if (lane == 0) *(lu32_t)(uintptr_t)(bb + 512u) = c.ev;
-                tn_band_advance(c);
-            }
+            if constexpr (!GATHER) lds_work(it, tb);
             phase(4);
             // the requests of block it+2 have landed before the barrier: the compute wavefront reads its first rows in the next
             // iteration
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             phase(3);
+        } else if (looker) {
+            lds_work(it, tb);
+        } else if (GATHER && it >= kb0 && it <= kb1) {
+            if constexpr (GATHER) {
+                uint32_t pairs = lds_pairs + (uint32_t)(it & 1) * kTgPairBytes, packets = c.lds_halo + ring(it) * (kTpBlock * 16);
+                asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(pairs), "=&v"(packets) : "s"(pairs), "s"(packets));
+                pairs += (uint32_t)lane * 8u;
+                asm volatile("" : "+v"(pairs));
+                {
+                    const uint32_t pk = lds_stage0 + (uint32_t)(it & 1) * kTpStageBytes;
+                    c.lds_stage = lane >= 62 ? pk + (uint32_t)(lane - 62) * 8u : pk + kTpBlock * 16 + (uint32_t)lane * 16u;
+                }
+                // the block's first four frames; the others are read four frames ahead (tg_frame)
+                TgIn in[4];
+                tg_read<0>(in[0], pairs, packets);
+                tg_read<1>(in[1], pairs, packets);
+                tg_read<2>(in[2], pairs, packets);
+                tg_read<3>(in[3], pairs, packets);
+                tg_wait_all(in);
+                H[0] = wave_shr1(in[0].hp[3], c.S[1]);   // position base + 2 lane - 1: the label of the lane below (lane 0: the packet's top cell)
+                H[1] = wave_shr1(in[0].hp[2], c.S[0]);   // - 2: its blank
+                H[2] = wave_shr1(in[0].hp[1], H[0]);     // - 3: the label two lanes below
+                const bool partial = (int32_t)tb < c.t_in || (int32_t)(tb + kTpBlock) > c.t_end;
+                const unsigned long long fr0 = (verify & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
+                if (!partial) {
+                    tg_block_frames<M, ZL, false, 0>(c, tb, H, in, pairs, packets, NINF);
+                    tg_wait_all(in);
+                    if ((tb + kTpBlock) % kCkFrames == 0 && tb + kTpBlock < c.T) tn_checkpoint(c, tb + kTpBlock);
+                } else {
+                    tg_block_frames<M, ZL, true, 0>(c, tb, H, in, pairs, packets, NINF);
+                    tg_wait_all(in);
+                    if ((tb + kTpBlock) % kCkFrames == 0 && (int32_t)(tb + kTpBlock) <= c.t_end && tb + kTpBlock < c.T) tn_checkpoint(c, tb + kTpBlock);
+                }
+                if (verify & 4) ((lu32_t)(uintptr_t)stat_lds)[2] += (uint32_t)(__builtin_amdgcn_s_memtime() - fr0);
+            }
         } else if (it >= kb0 && it <= kb1) {
-            const uint32_t slot = ring(it), nslot = ring(it + 1);
-            uint32_t rc = c.lds_rows + slot * kTpSlotBytes, rn = c.lds_rows + nslot * kTpSlotBytes;
-            uint32_t hc = c.lds_halo + slot * (kTpBlock * 16), hn = c.lds_halo + nslot * (kTpBlock * 16);
+            const uint32_t slot = rslot(it), nslot = rslot(it + 1);
+            uint32_t rc = c.lds_rows + slot * kRowSlot, rn = c.lds_rows + nslot * kRowSlot;
+            uint32_t hc = c.lds_halo + ring(it) * (kTpBlock * 16), hn = c.lds_halo + ring(it + 1) * (kTpBlock * 16);
             asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
                          : "=&v"(rc), "=&v"(rn), "=&v"(hc), "=&v"(hn) : "s"(rc), "s"(rn), "s"(hc), "s"(hn));
             TpAddr A[2] = {{rc + (uint32_t)c.la0, 0u, rc, hc}, {rn + (uint32_t)c.la0, 0u, rn, hn}};
@@ -465,16 +616,20 @@ __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     int32_t *m = meta_of(meta, d.idx);
-    if (feeder) {
+    if (feeder && !fed && lane == 0) atomicMin(&m[0], kStatusInternal);
+    if (GATHER ? looker : feeder) {
         // ---- finiteness (as forward_ck: the scores-only form is valid for finite log-probs of sane magnitude).  Flagged
         // before the tile reports itself done (barrier below), so that whoever closes the lattice sees the flag.
-        if ((!fed || stale) && lane == 0) atomicMin(&m[0], kStatusInternal);
+        if (stale && lane == 0) atomicMin(&m[0], kStatusInternal);
         const uint32_t abits = __builtin_bit_cast(uint32_t, c.absum) & 0x7fffffffu;
         if (__builtin_amdgcn_ballot_w64(abits > 0x7f800000u)) {
             if (lane == 0) atomicMin(&m[0], kStatusNaN);
         } else if (__builtin_amdgcn_ballot_w64(abits >= __builtin_bit_cast(uint32_t, 1e30f))) {
             if (lane == 0) atomicOr(&m[2], d.W <= kFastMaxBand ? kFlagExact : kFlagDeclined);
         }
+        __threadfence();
+    }
+    if (feeder) {
         // ---- hand the rest of the upper boundary over: after t_end the whole tile is below the band = -inf ----
         const f32x4 dead = {NINF, NINF, NINF, NINF};
         for (int64_t s = (int64_t)c.t_end + 1 + lane; s <= (int64_t)tk.fill_end; s += 64)
@@ -502,6 +657,7 @@ __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk
         }
         return;
     }
+    if (looker) return;
     // ---- terminal state: the HIGHEST live position of frame T-1 (align.py:99-101), over the tiles alive then ----
     if ((uint32_t)c.t_end == c.T) {
         // (the only full band mask of a tile's life: cells above hi may hold leaked scores)
@@ -542,15 +698,16 @@ __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk
     }
 }
 
-// One workgroup of two wavefronts per 128-position tile; launch parameters as forward_tp2_kernel's.
-template <int M, int PITCH, bool CONTIG>
-__global__ __launch_bounds__(128) void forward_tn_kernel(const Lattice *__restrict__ lats, const TileTask *__restrict__ tasks, int n_tasks,
+// One workgroup of two wavefronts per 128-position tile; launch parameters as forward_tp2_kernel's, TnLds<..>::kTotal bytes of LDS.
+template <int M, int PITCH, bool CONTIG, bool GATHER>
+__global__ __launch_bounds__(GATHER ? 192 : 128) void forward_tn_kernel(const Lattice *__restrict__ lats, const TileTask *__restrict__ tasks, int n_tasks,
                                                          int32_t *meta, char *halo, uint32_t *prog, TileAux *aux, uint32_t *ticket, int verify, TpStats *stats)
 {
     extern __shared__ __attribute__((aligned(16))) char tp_lds[];
     const uint32_t lds_rows = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&tp_lds[0];
-    const uint32_t lds_halo = lds_rows + kTpRing * kTpSlotBytes;
-    volatile uint32_t *s_ticket = reinterpret_cast<volatile uint32_t *>(&tp_lds[kTpRing * kTpSlotBytes + kTpRing * kTpBlock * 16 + 16 + kTp2StageBytes + 48]);
+    typedef TnLds<PITCH, CONTIG, GATHER> Lds;
+    const uint32_t lds_halo = lds_rows + Lds::kHalo;
+    volatile uint32_t *s_ticket = reinterpret_cast<volatile uint32_t *>(&tp_lds[Lds::kStat + 48]);
     if (threadIdx.x == 0) *s_ticket = atomicAdd(ticket, 1u);
     __syncthreads();
     const uint32_t tix = (uint32_t)__builtin_amdgcn_readfirstlane((int)*s_ticket);
@@ -560,9 +717,9 @@ __global__ __launch_bounds__(128) void forward_tn_kernel(const Lattice *__restri
     const Lattice &d = lats[__builtin_amdgcn_readfirstlane(tk.lat)];
     const int flags = __builtin_amdgcn_readfirstlane(meta_of(meta, d.idx)[2]);
     if (flags & kFlagZeroLabel)
-        tn_run_tile<M, true, PITCH, CONTIG>(d, tk, meta, halo, (gu32w_t)prog, aux, lds_rows, lds_halo, verify, stats + tix);
+        tn_run_tile<M, true, PITCH, CONTIG, GATHER>(d, tk, meta, halo, (gu32w_t)prog, aux, lds_rows, lds_halo, verify, stats + tix);
     else
-        tn_run_tile<M, false, PITCH, CONTIG>(d, tk, meta, halo, (gu32w_t)prog, aux, lds_rows, lds_halo, verify, stats + tix);
+        tn_run_tile<M, false, PITCH, CONTIG, GATHER>(d, tk, meta, halo, (gu32w_t)prog, aux, lds_rows, lds_halo, verify, stats + tix);
 }
 
 }  // namespace ka

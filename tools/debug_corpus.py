@@ -14,6 +14,8 @@ for (T, S), seed in zip(shapes, seeds):
     a, b_ = W.device_book([(T, S)], seed0=seed); lps += a; labs += b_
 b = DeviceBatch(lps, labs)
 e = b.engine
+e.set_tile_width(int(os.environ.get("KA_TILE_WIDTH", "0")))     # 0: the library chooses; 128 / 256 forced
+e.set_tile_gather(int(os.environ.get("KA_TILE_GATHER", "-1")))
 def run(mode, bt, waves, split=(-1, -1)):
     e.set_mode(mode); e.set_backtrace(bt); e.set_tile_waves(waves); e.set_split(*split)
     st = b.run(raise_on_error=False)
@@ -28,4 +30,4 @@ for cfg in [("tiled", "serial", 2)] * reps + [("tiled", "parallel", 2), ("tiled"
     for i in bad[:3]:
         d = (ref[i] != p[i]).nonzero().flatten()
         print("   lattice", i, "T", shapes[i][0], "first diff frame", int(d[0]), "last", int(d[-1]), "count", len(d), flush=True)
-e.set_mode("auto"); e.set_backtrace("auto"); e.set_split(-1, -1)
+e.set_mode("auto"); e.set_backtrace("auto"); e.set_split(-1, -1); e.set_tile_width(0)

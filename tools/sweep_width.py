@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Tile width of the tiled form (256 or 128 positions) against the number of lattices in the launch: forward kernel time of
-the first K chapters of the corpus stand-in, all tiled, for both widths - the data behind the engine's choice (ka_engine.hip,
-"tile width").   python tools/sweep_width.py [K ...]"""
+"""Tile width of the tiled form (256 positions, 128, 128 with the emissions looked up by the feeder wavefront) against the
+number of lattices in the launch: forward kernel time of the first K chapters of the corpus stand-in, all tiled, for each -
+the data behind the engine's choice (ka_engine.hip, "tile width").   python tools/sweep_width.py [K ...]"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -18,20 +18,21 @@ for K in Ks:
     b.engine.set_profiling(True)
     row = {"lattices": K, "frames": sum(t for t, _ in shapes), "longest": max(t for t, _ in shapes)}
     ref = None
-    for width in (256, 128):
+    for width, gather in ((256, -1), (128, 0), (128, 1)):
         b.engine.set_tile_width(width)
+        b.engine.set_tile_gather(gather)
         b.run()
         ms = []
         for _ in range(3):
             b.run()
             ms.append(b.engine.last_kernel_ms()["forward"])
-        row[f"forward_ms_{width}"] = round(min(ms), 4)
+        row[f"forward_ms_{width}" + ("_feeder_lookup" if gather == 1 else "")] = round(min(ms), 4)
         paths = [p.clone() for p in b.path]
         if ref is None:
             ref = paths
         else:
-            row["same_paths"] = all(torch.equal(a, c) for a, c in zip(ref, paths))
+            row["same_paths"] = row.get("same_paths", True) and all(torch.equal(a, c) for a, c in zip(ref, paths))
     print(json.dumps(row), flush=True)
-    b.engine.set_tile_width(0); b.engine.set_mode("auto"); b.engine.set_profiling(False)
+    b.engine.set_tile_width(0); b.engine.set_tile_gather(-1); b.engine.set_mode("auto"); b.engine.set_profiling(False)
     del b, lps, labs
     torch.cuda.empty_cache()
