@@ -920,6 +920,7 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
             const bool has_above = b + 1 < p.t_in.size();
             tk.halo_out = (int64_t)bound[key.k][b];
             tk.fill_end = has_above ? p.t_end[b + 1] - 1 : 0;
+            tk.below_end = b == 0 ? INT32_MAX : p.t_end[b - 1];
             tk.prog_in = b == 0 ? 0 : (int32_t)(first_word[key.k] + b - 1);
             tk.prog_out = (int32_t)(first_word[key.k] + b);
         }

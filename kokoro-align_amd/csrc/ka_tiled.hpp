@@ -49,7 +49,7 @@ struct TileTask {
     int32_t fill_end;   // last slot of the upper boundary that the tile above reads (its t_end - 1)
     int32_t prog_in;    // progress word of the tile below (word 0 holds kTpProgDone: nothing below tile 0)
     int32_t prog_out;   // progress word of this tile
-    int32_t pad;
+    int32_t below_end;  // t_end of the tile below (tile 0: INT32_MAX): the slots behind it hold -inf by construction (ka_tiled_narrow.hpp uses it)
 };
 // per lattice, zeroed before every launch: terminal state by 64-bit atomicMax, arrival counter of the last-frame tiles
 struct TileAux {

@@ -374,13 +374,21 @@ __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk
     typedef __attribute__((address_space(3))) void *lptr_t;
     typedef __attribute__((address_space(3))) char *lchar_t;
     const uint32_t last_row = c.T - 1;
-    const uint32_t last_slot = (uint32_t)c.t_end - 1;     // this tile reads slots t_in .. t_end - 1
+    // This tile reads slots t_in .. t_end - 1 of the boundary below.  The tile below computes frames < below_end, so its slots
+    // <= below_end are states it computed and every slot behind them is -inf BY CONSTRUCTION (it is under the band): it stores
+    // ONE of those, slot below_end + 1, with its last block, and this tile reads that one for all of them and never asks for
+    // progress beyond it.  (ka_tiled2.hpp fills all the slots behind t_end after its loop and the tile above waits for the
+    // "done" word: ~3 us per tile boundary in which the chain's new front - the tile above, when this one dies - stands still.)
+    const uint32_t below_end = (uint32_t)__builtin_amdgcn_readfirstlane(tk.below_end);
+    const int32_t fill_end = __builtin_amdgcn_readfirstlane(tk.fill_end);      // last slot of the boundary above that the tile above reads
+    const uint32_t dead_slot = below_end < 0x7ffffff0u ? below_end + 1u : 0x7fffffffu;
+    const uint32_t last_slot = (uint32_t)c.t_end - 1 < dead_slot ? (uint32_t)c.t_end - 1 : dead_slot;
     auto ring = [](int32_t k) { return (uint32_t)((k % kTpRing + kTpRing) % kTpRing); };            // packets and poll words
     auto rslot = [](int32_t k) { return (uint32_t)((k % kRowRing + kRowRing) % kRowRing); };        // rows
     constexpr int kRowDmas = Lds::kRowDmas;   // LDS-DMA instructions per block of rows
     static_assert(CONTIG || PITCH == kTpRowBytes, "row-by-row staging uses 256-byte rows");
-    auto issue_block = [&](int32_t k) {    // k >= 0
-        const uint32_t tb = (uint32_t)k * kTpBlock, slot = ring(k);
+    auto issue_rows = [&](int32_t k) {    // k >= 0: the log-prob rows of block k (they do not depend on the tile below)
+        const uint32_t tb = (uint32_t)k * kTpBlock;
         lchar_t dst = (lchar_t)(uintptr_t)(c.lds_rows + rslot(k) * kRowSlot);
         if constexpr (!CONTIG) {
             const char *rp = c.lp + (size_t)(tb < last_row ? tb : last_row) * c.ld;
@@ -409,6 +417,9 @@ __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk
                 __builtin_amdgcn_global_load_lds((gptr_t)(bp + off), (lptr_t)(dst + j * 1024), 16, 0, 0);
             }
         }
+    };
+    auto issue_packets = [&](int32_t k) {    // k >= 0: the tile below's packets of block k, and a look at its progress word
+        const uint32_t tb = (uint32_t)k * kTpBlock, slot = ring(k);
         if (lane < kTpBlock) {
             uint32_t s = tb + (uint32_t)lane;
             s = s < (uint32_t)c.t_in ? (uint32_t)c.t_in : (s > last_slot ? last_slot : s);
@@ -416,18 +427,14 @@ __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk
         }
         if (lane == 0) __builtin_amdgcn_global_load_lds((gptr_t)c.prog_in, (lptr_t)(lchar_t)(uintptr_t)(lds_poll + slot * 4), 4, 0, 16);
     };
+    auto issue_block = [&](int32_t k) {
+        issue_rows(k);
+        issue_packets(k);
+    };
     bool stale = false;
-    auto landed_block = [&](int32_t k) {
-        const uint32_t slot = ring(k);
-        const uint32_t r = c.lds_rows + rslot(k) * kRowSlot + (uint32_t)lane * 16u;
-        constexpr int kReads = !CONTIG ? kTpSlotBytes / 1024 : kRowDmas;
-        f32x4 v[kReads];
-#pragma unroll
-        for (int j = 0; j < kReads; ++j) v[j] = lds_f32x4(r + j * 1024);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int j = 0; j < kReads; ++j) c.absum += (__builtin_fabsf(v[j][0]) + __builtin_fabsf(v[j][1])) + (__builtin_fabsf(v[j][2]) + __builtin_fabsf(v[j][3]));
+    auto check_packets = [&](int32_t k) {      // ka_engine_set_verify(1): a packet of block k (landed) that nobody wrote
         if (verify & 1) {
+            const uint32_t slot = ring(k);
             const int32_t sidx = k * kTpBlock + (lane & (kTpBlock - 1));
             const f32x4 h = lds_f32x4(c.lds_halo + slot * (kTpBlock * 16) + (uint32_t)(lane & (kTpBlock - 1)) * 16u);
             const bool mine = lane < kTpBlock && sidx >= c.t_in && sidx < c.t_end;
@@ -436,9 +443,21 @@ __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk
             if (__builtin_amdgcn_ballot_w64(bad)) stale = true;
         }
     };
-    auto need_for = [&](int32_t k) {
-        const uint32_t n = (uint32_t)(k + 1) * kTpBlock;
-        return n < (uint32_t)c.t_end ? n : (uint32_t)c.t_end;
+    auto landed_block = [&](int32_t k) {
+        const uint32_t r = c.lds_rows + rslot(k) * kRowSlot + (uint32_t)lane * 16u;
+        constexpr int kReads = !CONTIG ? kTpSlotBytes / 1024 : kRowDmas;
+        f32x4 v[kReads];
+#pragma unroll
+        for (int j = 0; j < kReads; ++j) v[j] = lds_f32x4(r + j * 1024);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < kReads; ++j) c.absum += (__builtin_fabsf(v[j][0]) + __builtin_fabsf(v[j][1])) + (__builtin_fabsf(v[j][2]) + __builtin_fabsf(v[j][3]));
+        if constexpr (!GATHER) check_packets(k);
+    };
+    auto need_for = [&](int32_t k) {      // progress word the tile below must show before block k's packets are requested (slots < it)
+        uint32_t n = (uint32_t)(k + 1) * kTpBlock;
+        n = n < (uint32_t)c.t_end ? n : (uint32_t)c.t_end;
+        return n < dead_slot + 1u ? n : dead_slot + 1u;
     };
 
     const int32_t kb0 = c.t_in / kTpBlock, kb1 = (c.t_end - 1) / kTpBlock;   // first and last block
@@ -500,28 +519,48 @@ __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk
             //     it+2, publish, ONE wait for both, announce;
             //   else: publish, wait, announce - then poll, request, and wait again at the end of the iteration.
             // (No counted waits: vmcnt orders loads among loads and stores among stores, not one against the other.)
+            // GATHER form: the compute wavefront reads nothing of the next block, so the packets of block it+1 are requested in
+            // iteration it - ONE block ahead, a block of lag less per tile boundary - and the rows, which do not depend on the tile
+            // below, two ahead as before (the look-up wavefront needs block it+1's in this iteration).
+            constexpr int kAhead = GATHER ? 1 : 2;
             const bool published = it - 1 >= kb0 && it - 1 <= kb1;
-            const bool wanted = it + 2 <= kb1 && fed;                  // block it+2 has packets of the tile below to wait for
-            const uint32_t have = wanted && it + 1 >= kb0 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_bit_cast(uint32_t, lds_f32(lds_poll + ring(it + 1) * 4))) : 0u;
-            const bool ready = !wanted || have >= need_for(it + 2);
-            const bool request = it + 2 >= 0 && it + 2 <= kb1 + 1;
-            if (ready && request) issue_block(it + 2);
+            const bool wanted = it + kAhead <= kb1 && fed;            // that block has packets of the tile below to wait for
+            const uint32_t have = wanted && it + kAhead - 1 >= kb0
+                                      ? (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_bit_cast(uint32_t, lds_f32(lds_poll + ring(it + kAhead - 1) * 4))) : 0u;
+            const bool ready = !wanted || have >= need_for(it + kAhead);
+            const bool request = GATHER ? (it + 1 >= 0 && it + 1 <= kb1) : (it + 2 >= 0 && it + 2 <= kb1 + 1);
+            if constexpr (GATHER) {
+                if (it + 2 >= 0 && it + 2 <= kb1) issue_rows(it + 2);
+                if (ready && request) issue_packets(it + 1);
+            } else {
+                if (ready && request) issue_block(it + 2);
+            }
             phase(6);
             if (published) {
                 c.lds_packets = lds_stage0 + (uint32_t)((it - 1) & 1) * kTpStageBytes;
                 tn_publish_block(c, tb - kTpBlock, lane);
+                // with the last block, the one -inf slot that stands for everything behind t_end (the tile above reads slots up to
+                // its own t_end - 1 = fill_end: none behind t_end when the two end together)
+                const bool closing = tb >= (uint32_t)c.t_end && c.t_end <= fill_end;
+                if (closing && lane == 0) {
+                    const f32x4 dead = {NINF, NINF, NINF, NINF};
+                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" : : "v"((uint32_t)((c.t_end + 1 - c.t_in) * 16)), "v"(dead), "s"(c.halo_out) : "memory");
+                }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                // slots <= tb are in memory - but never vouch for more than the tile's own frames have produced: the slots behind
-                // t_end are filled (with -inf) after the loop, and the final progress word covers those
-                tp_prog_store(c.prog_out, (tb < (uint32_t)c.t_end ? tb : (uint32_t)c.t_end) + 1);
+                // slots <= tb are in memory - but never vouch for more than the tile's own frames have produced
+                tp_prog_store(c.prog_out, (tb < (uint32_t)c.t_end ? tb : (uint32_t)c.t_end) + 1 + (closing ? 1u : 0u));
             }
             phase(7);
             if (!ready) {
                 // (no hysteresis: the one-wavefront tile asks for two blocks more than it needs once it has to wait, so that its
                 //  frames are not interrupted by a poll per block; here the frames run in the other wavefront)
-                fed = tp_wait_progress(c.prog_in, need_for(it + 2), need_for(it + 2), have, stat_lds);
+                fed = tp_wait_progress(c.prog_in, need_for(it + kAhead), need_for(it + kAhead), have, stat_lds);
                 phase(5);
-                if (request) issue_block(it + 2);
+                if constexpr (GATHER) {
+                    if (request) issue_packets(it + 1);
+                } else {
+                    if (request) issue_block(it + 2);
+                }
             }
             phase(6);
             if constexpr (!GATHER) lds_work(it, tb);
@@ -531,6 +570,7 @@ __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             phase(3);
         } else if (looker) {
+            if (it >= kb0 && it <= kb1) check_packets(it);
             lds_work(it, tb);
         } else if (GATHER && it >= kb0 && it <= kb1) {
             if constexpr (GATHER) {
@@ -630,11 +670,7 @@ __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk
         __threadfence();
     }
     if (feeder) {
-        // ---- hand the rest of the upper boundary over: after t_end the whole tile is below the band = -inf ----
-        const f32x4 dead = {NINF, NINF, NINF, NINF};
-        for (int64_t s = (int64_t)c.t_end + 1 + lane; s <= (int64_t)tk.fill_end; s += 64)
-            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" : : "v"((uint32_t)((s - c.t_in) * 16)), "v"(dead), "s"(c.halo_out) : "memory");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (nothing to hand over behind t_end: the one -inf slot went out with the last block)
         tp_prog_store(c.prog_out, kTpProgDone);
         __threadfence();
     }
