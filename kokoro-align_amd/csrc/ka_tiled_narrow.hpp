@@ -248,9 +248,10 @@ __device__ __forceinline__ void tg_frame(TnTile<M, ZL> &c, uint32_t t, float (&H
         c.S = f32x2{mb, ml} + in[0].e;
     }
     if constexpr (F + 1 < kTpBlock) {
-        // frame F+1's pair and packet: primed (F + 1 < 4), else read in frame F-3 - the instructions of frames F-2 and F-1 may
-        // still be in flight
+        // frame F+1's pair and packet: read in frame F-3 - the instructions of frames F-2 and F-1 may still be in flight - or,
+        // F + 1 < 4, with the block's first four: behind them came the reads of frames F+2 .. 3 and everything frames 0 .. F-1 issued
         if constexpr (F >= 3) tg_wait<tg_ops(F - 2) + tg_ops(F - 1)>(in[1]);
+        else tg_wait<2 * (2 - F) + 3 * F>(in[1]);
         H[0] = wave_shr1(in[1].hp[3], c.S[1]);
         H[1] = wave_shr1(in[1].hp[2], c.S[0]);
         H[2] = wave_shr1(in[1].hp[1], H[0]);
@@ -296,6 +297,8 @@ __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk
     // block against the compute wavefront's 2500
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const bool feeder = role == 1, looker = GATHER && role == 2;
+    // the compute wavefront is the chain: where it shares a SIMD with other tiles' feeders and look-up wavefronts it issues first
+    if (role == 0) __builtin_amdgcn_s_setprio(3);
     typedef TnLds<PITCH, CONTIG, GATHER> Lds;
     constexpr int kRowRing = Lds::kRing, kRowSlot = Lds::kSlot;
     const uint32_t lds_poll = lds_rows + Lds::kPoll;
@@ -588,7 +591,7 @@ __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk
                 tg_read<1>(in[1], pairs, packets);
                 tg_read<2>(in[2], pairs, packets);
                 tg_read<3>(in[3], pairs, packets);
-                tg_wait_all(in);
+                tg_wait<6>(in[0]);      // (the first frame's; the other three land while it runs)
                 H[0] = wave_shr1(in[0].hp[3], c.S[1]);   // position base + 2 lane - 1: the label of the lane below (lane 0: the packet's top cell)
                 H[1] = wave_shr1(in[0].hp[2], c.S[0]);   // - 2: its blank
                 H[2] = wave_shr1(in[0].hp[1], H[0]);     // - 3: the label two lanes below
