@@ -176,6 +176,10 @@ int ka_debug_set_tile_width(ka_engine *e, int32_t positions);
  * of LDS per tile instead of 40: two or three tiles per CU), 0 = the compute wavefront reads the staged rows itself, -1 = the
  * library's choice.  Results are identical. */
 int ka_debug_set_tile_gather(ka_engine *e, int32_t how);
+/* Host-side probe of the library's choice (no GPU needed): the tile width - 128 or 256 - a launch of these n lattices, ALL run in
+ * the tiled form, gets on a device of n_simd SIMDs; 0 if one of them is not run in the tiled form at all, a negative status for
+ * bad arguments. */
+int ka_debug_tile_width_choice(const int64_t *T, const int64_t *S, int32_t n, int32_t V, int32_t beam_size, int32_t max_move, int32_t n_simd);
 /* The serial backtrace's output form: 1 = labels and scores gathered from memory after the walk (fewer vector instructions:
  * launches that fill the chip; by the counters 17 % more HBM traffic per step), 0 or -1 (default) = collected by the walk in
  * registers.  Results are identical. */

@@ -35,7 +35,7 @@ EXPORTS = [
     "ka_debug_tile_stats", "ka_engine_set_backtrace", "ka_debug_chunk_entries", "ka_debug_plan_tiles",
     "ka_engine_set_verify", "ka_stream_create", "ka_stream_destroy", "ka_engine_set_tile_waves",
     "ka_debug_set_split", "ka_engine_workspace_bytes", "ka_debug_set_tile_lds",
-    "ka_debug_auto_split", "ka_debug_set_rc_gather", "ka_lstm_layer0_f32", "ka_debug_set_tile_width", "ka_debug_set_tile_gather", "ka_debug_plan_tiles_width",
+    "ka_debug_auto_split", "ka_debug_set_rc_gather", "ka_lstm_layer0_f32", "ka_debug_set_tile_width", "ka_debug_set_tile_gather", "ka_debug_tile_width_choice", "ka_debug_plan_tiles_width",
 ]
 
 
@@ -108,6 +108,8 @@ def load_library():
     L.ka_debug_set_rc_gather.argtypes = [vp, i32]
     L.ka_debug_set_tile_lds.restype = ctypes.c_int
     L.ka_debug_set_tile_lds.argtypes = [vp, i32]
+    L.ka_debug_tile_width_choice.restype = ctypes.c_int
+    L.ka_debug_tile_width_choice.argtypes = [vp, vp, i32, i32, i32, i32, i32]
     L.ka_debug_set_tile_gather.restype = ctypes.c_int
     L.ka_debug_set_tile_gather.argtypes = [vp, i32]
     L.ka_debug_set_tile_width.restype = ctypes.c_int

@@ -131,6 +131,29 @@ void plan_tiles(Shape &sh, int32_t V, int32_t beam, int32_t max_move, int64_t P 
     sh.tileable = true;
 }
 
+// Tile width of a launch's tiled lattices: 128 positions (two cells per lane and three wavefronts per tile, ka_tiled_narrow.hpp:
+// a frame of half the instructions, twice the tiles and twice the hand-offs, 48-56 KB of LDS per tile) while the tiles alive
+// at once are no more than 2.6 per workgroup slot of the device, else 256.  Measured on prefixes of the corpus stand-in, all
+// tiled, V = 39: three workgroups per CU (tools/sweep_width.py, profiles/r03_sweep_width.jsonl): against 256 positions the
+// forward kernel takes 0.66 x the time for one chapter, 0.70 x for 64 (~580 tiles alive), 0.78 x for 128, 0.94 x for 200 (~1800),
+// 1.17 x for 320 (~2900).  Tiles that never die (a band as wide as the label axis) must all hold a slot at once: the whole
+// 500 000 x 100 001 lattice, 782 tiles of 128 positions on 512 slots, took 89 ms instead of 56.
+// `plans`: the 128-position plan of every tiled lattice (tileable or not).  forced: 0 = by the rule, 128, 256.
+bool narrow_tiles_pay(const std::vector<Shape> &plans, int32_t V, int32_t max_move, int32_t n_simd, int32_t forced)
+{
+    if (forced == ka::kTpTile || plans.empty()) return false;
+    int64_t alive_now = 0, permanent = 0;     // tiles alive at once: of banded lattices (they come and go), of those that are all band
+    for (const Shape &p : plans) {
+        if (!p.tileable) return false;        // (L/T above 128: the band jumps over a whole tile in one frame)
+        const int64_t n_tiles = (int64_t)p.t_in.size(), in_band = (p.W + 2 * ka::kTnTile - 1) / ka::kTnTile;
+        if (n_tiles <= in_band) permanent += n_tiles;
+        else alive_now += in_band;
+    }
+    if (forced == ka::kTnTile) return true;
+    const int64_t slots = (int64_t)(n_simd / 4) * ((V == 39 && max_move == 4) ? 3 : 2);   // (V = 39: 47.5 KB per workgroup, else 55.5)
+    return permanent <= slots && 5 * alive_now <= 13 * (slots - permanent);
+}
+
 bool shape_of(int64_t T, int64_t S, int32_t V, int32_t beam, int32_t max_move, Shape &sh)
 {
     if (T < 1 || S < 0 || V < 1 || beam < 0 || max_move < 1 || max_move > 255) return false;
@@ -671,30 +694,17 @@ static int enqueue_impl(ka_engine *e, int32_t n, const float *const *log_probs, 
         }
         for (int32_t i = 0; i < n; ++i) n_tiled += sh[i].tiled ? 1 : 0;
     }
-    // ---- tile width: 128 positions (two cells per lane and three wavefronts per tile, ka_tiled_narrow.hpp: a frame of half the
-    // instructions, twice the tiles and twice the hand-offs, 48-56 KB of LDS per tile) while the tiles alive at once are no
-    // more than 2.6 per workgroup slot of the device, else 256.  Measured on prefixes of the corpus stand-in, all tiled, V = 39:
-    // three workgroups per CU (tools/sweep_width.py, profiles/r03_sweep_width.jsonl): against 256 positions the forward kernel
-    // takes 0.66 x the time for one chapter, 0.71 x for 64 (~580 tiles alive), 0.77 x for 120, 0.93 x for 200 (~1800), 1.17 x for 320 (~2900).
+    // ---- tile width (narrow_tiles_pay above) ----
     bool narrow = false;
     if (n_tiled > 0 && e->tile_waves == 2 && e->tile_width != ka::kTpTile) {
         std::vector<Shape> alt;
-        int64_t alive_now = 0, permanent = 0;     // tiles alive at once: of banded lattices (they come and go), of lattices whose band is the whole label axis
-        bool ok = true;
-        for (int32_t i = 0; i < n && ok; ++i) {
+        for (int32_t i = 0; i < n; ++i) {
             if (!sh[i].tiled) continue;
             Shape p = sh[i];
             plan_tiles(p, V, beam_size, max_move, ka::kTnTile);
-            ok = p.tileable;
-            const int64_t n_tiles = (int64_t)p.t_in.size(), in_band = (p.W + 2 * ka::kTnTile - 1) / ka::kTnTile;
-            if (n_tiles <= in_band) permanent += n_tiles;
-            else alive_now += in_band;
             alt.push_back(std::move(p));
         }
-        const int64_t slots = (int64_t)(e->n_simd / 4) * ((V == 39 && max_move == 4) ? 3 : 2);   // (V = 39: 47.5 KB per workgroup, else 55.5)
-        // (tiles that never die must all hold a slot at once: the whole 500 000 x 100 001 lattice, 782 tiles of 128 positions on 512
-        //  slots, took 89 ms instead of 56)
-        if (ok && (e->tile_width == ka::kTnTile || (permanent <= slots && 5 * alive_now <= 13 * (slots - permanent)))) {
+        if (narrow_tiles_pay(alt, V, max_move, e->n_simd, e->tile_width)) {
             narrow = true;
             size_t j = 0;
             for (int32_t i = 0; i < n; ++i)
@@ -1279,6 +1289,19 @@ int ka_debug_plan_tiles_width(int64_t T, int64_t S, int32_t V, int32_t beam_size
     }
     if (checkpoint_pitch) *checkpoint_pitch = (int64_t)sh.ck_pitch;
     return (int)sh.t_in.size();
+}
+
+int ka_debug_tile_width_choice(const int64_t *T, const int64_t *S, int32_t n, int32_t V, int32_t beam_size, int32_t max_move, int32_t n_simd)
+{
+    if (n < 0 || (n > 0 && (!T || !S)) || n_simd < 4) return fail(KA_ERR_BAD_ARGS, "ka_debug_tile_width_choice: bad arguments");
+    std::vector<Shape> plans(n);
+    for (int32_t i = 0; i < n; ++i) {
+        if (!shape_of(T[i], S[i], V, beam_size, max_move, plans[i])) return fail(KA_ERR_BAD_ARGS, "ka_debug_tile_width_choice: bad shape");
+        plan_tiles(plans[i], V, beam_size, max_move, ka::kTpTile);
+        if (!plans[i].tileable) return 0;
+        plan_tiles(plans[i], V, beam_size, max_move, ka::kTnTile);
+    }
+    return narrow_tiles_pay(plans, V, max_move, n_simd, 0) ? ka::kTnTile : ka::kTpTile;
 }
 
 int ka_debug_auto_split(const int64_t *T, int32_t n, int32_t tiles_alive, int32_t n_simd, int32_t *n_tiled, int32_t *n_parallel)
