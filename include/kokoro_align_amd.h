@@ -172,8 +172,8 @@ int ka_debug_set_tile_lds(ka_engine *e, int32_t bytes);
  * the tiles; only with two wavefronts per tile), or 0 = the library's choice (128 when all the launch's tiles are alive on
  * no more than half the device's SIMDs).  Results are identical. */
 int ka_debug_set_tile_width(ka_engine *e, int32_t positions);
-/* 128-position tiles: 1 = the feeder wavefront looks up the emissions of a block and folds the band's kills into them (48-56 KB
- * of LDS per tile instead of 40: two or three tiles per CU), 0 = the compute wavefront reads the staged rows itself, -1 = the
+/* 128-position tiles: 1 = the feeder wavefront looks up the emissions of a block and folds the band's kills into them (46-52 KB
+ * of LDS per tile instead of 40: three tiles per CU), 0 = the compute wavefront reads the staged rows itself, -1 = the
  * library's choice.  Results are identical. */
 int ka_debug_set_tile_gather(ka_engine *e, int32_t how);
 /* Host-side probe of the library's choice (no GPU needed): the tile width - 128 or 256 - a launch of these n lattices, ALL run in

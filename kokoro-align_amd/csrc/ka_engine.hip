@@ -132,7 +132,7 @@ void plan_tiles(Shape &sh, int32_t V, int32_t beam, int32_t max_move, int64_t P 
 }
 
 // Tile width of a launch's tiled lattices: 128 positions (two cells per lane and three wavefronts per tile, ka_tiled_narrow.hpp:
-// a frame of half the instructions, twice the tiles and twice the hand-offs, 48-56 KB of LDS per tile) while the tiles alive
+// a frame of half the instructions, twice the tiles and twice the hand-offs, 46-52 KB of LDS per tile) while the tiles alive
 // at once are no more than 2.6 per workgroup slot of the device, else 256.  Measured on prefixes of the corpus stand-in, all
 // tiled, V = 39: three workgroups per CU (tools/sweep_width.py, profiles/r03_sweep_width.jsonl): against 256 positions the
 // forward kernel takes 0.66 x the time for one chapter, 0.70 x for 64 (~580 tiles alive), 0.78 x for 128, 0.94 x for 200 (~1800),
@@ -150,7 +150,8 @@ bool narrow_tiles_pay(const std::vector<Shape> &plans, int32_t V, int32_t max_mo
         else alive_now += in_band;
     }
     if (forced == ka::kTnTile) return true;
-    const int64_t slots = (int64_t)(n_simd / 4) * ((V == 39 && max_move == 4) ? 3 : 2);   // (V = 39: 47.5 KB per workgroup, else 55.5)
+    (void)V; (void)max_move;
+    const int64_t slots = (int64_t)(n_simd / 4) * 3;   // 46-52 KB of LDS per workgroup: three per CU
     return permanent <= slots && 5 * alive_now <= 13 * (slots - permanent);
 }
 

@@ -199,7 +199,7 @@ __device__ __forceinline__ void tn_block_frames(TnTile<M, ZL> &c, uint32_t tb, f
 // not cross into the next block (whose pairs the feeder is writing during this iteration): four frames are primed at the
 // start of a block, the last four frames read nothing, and the hand-written waits count accordingly.
 // LDS: 2 x 16 KB of pairs; the compute wavefront no longer reads rows, so two row slots do (the block being looked up and
-// the one landing) - 47.5 KB per workgroup for V = 39 (three per CU), 55.5 KB for V = 64 (two).
+// the one landing), and two packet slots - 46.1 KB per workgroup for V = 39, 52.1 KB for V = 64: three per CU.
 // ---------------------------------------------------------------------------------------
 constexpr int kTgPairBytes = kTpBlock * 64 * 8;
 template <int PITCH, bool CONTIG, bool GATHER>
@@ -207,14 +207,18 @@ struct TnLds {
     static constexpr int kRowDmas = !CONTIG ? kTpBlock : (kTpBlock * PITCH + 1023) / 1024;
     static constexpr int kRing = GATHER ? 2 : kTpRing;                                        // row slots
     static constexpr int kSlot = GATHER && CONTIG ? kRowDmas * 1024 : kTpSlotBytes;           // bytes per row slot
-    static constexpr int kHalo = kRing * kSlot;                                               // packets of the tile below: kTpRing slots of 32
-    static constexpr int kPoll = kHalo + kTpRing * kTpBlock * 16;
+    static constexpr int kPkRing = GATHER ? 2 : kTpRing;                                      // packet slots (GATHER: the block being read, the one landing)
+    static constexpr int kStageBytes = GATHER ? 1536 : kTpStageBytes;                         // a publish staging buffer (GATHER: the idle lanes' scratch 8 bytes apart)
+    static constexpr int kHalo = kRing * kSlot;                                               // packets of the tile below: kPkRing slots of 32
+    static constexpr int kPoll = kHalo + kPkRing * kTpBlock * 16;
     static constexpr int kStage = kPoll + 16;
-    static constexpr int kStat = kStage + kTp2StageBytes;                                     // 12 diagnostic words, the ticket at +48
+    static constexpr int kStat = kStage + 2 * kStageBytes;                                     // 12 diagnostic words, the ticket at +48
     static constexpr int kBand = kStat + 64;                                                  // !GATHER: two band buffers;  GATHER: two pair buffers
     static constexpr int kTotal = kBand + (GATHER ? 2 * kTgPairBytes : 2 * kTp2BandBytes);
 };
 static_assert(TnLds<256, true, false>::kTotal <= (int)kTpLdsRequest, "LDS budget of the narrow tile");
+static_assert(3 * ((TnLds<256, true, true>::kTotal + 511) / 512 * 512) <= 160 * 1024 && 3 * ((TnLds<256, false, true>::kTotal + 511) / 512 * 512) <= 160 * 1024,
+              "three look-up workgroups per CU");
 
 struct TgIn {
     f32x2 e;      // {blank emission, label emission} of the lane's two cells, -inf where the cell dies after the frame
@@ -346,7 +350,8 @@ __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk
     c.ck_off = (((uint32_t)c.base + (uint32_t)kTnCells * (uint32_t)lane) & (uint32_t)d.ck_mask) * 4u;
     c.lds_rows = lds_rows;
     c.lds_halo = lds_halo;
-    static_assert(kTpBlock * 16 + 62 * 16 + (kTpBlock - 1) * 16 + 16 <= kTpStageBytes, "publish staging");
+    constexpr int kStageBytes = Lds::kStageBytes, kScratch = GATHER ? 8 : 16;     // idle lanes' scratch behind the packet rows: bytes per lane
+    static_assert(kTpBlock * 16 + 61 * kScratch + (kTpBlock - 1) * 16 + 8 <= kStageBytes, "publish staging");
     const auto uni = [](uint64_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v); };
     {
         const uint64_t x = (uint64_t)c.L * (uint64_t)((uint32_t)c.t_in / kTpBlock * kTpBlock);
@@ -386,7 +391,8 @@ __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk
     const int32_t fill_end = __builtin_amdgcn_readfirstlane(tk.fill_end);      // last slot of the boundary above that the tile above reads
     const uint32_t dead_slot = below_end < 0x7ffffff0u ? below_end + 1u : 0x7fffffffu;
     const uint32_t last_slot = (uint32_t)c.t_end - 1 < dead_slot ? (uint32_t)c.t_end - 1 : dead_slot;
-    auto ring = [](int32_t k) { return (uint32_t)((k % kTpRing + kTpRing) % kTpRing); };            // packets and poll words
+    constexpr int kPkRing = Lds::kPkRing;
+    auto ring = [](int32_t k) { return (uint32_t)((k % kPkRing + kPkRing) % kPkRing); };            // packets and poll words
     auto rslot = [](int32_t k) { return (uint32_t)((k % kRowRing + kRowRing) % kRowRing); };        // rows
     constexpr int kRowDmas = Lds::kRowDmas;   // LDS-DMA instructions per block of rows
     static_assert(CONTIG || PITCH == kTpRowBytes, "row-by-row staging uses 256-byte rows");
@@ -540,7 +546,7 @@ __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk
             }
             phase(6);
             if (published) {
-                c.lds_packets = lds_stage0 + (uint32_t)((it - 1) & 1) * kTpStageBytes;
+                c.lds_packets = lds_stage0 + (uint32_t)((it - 1) & 1) * kStageBytes;
                 tn_publish_block(c, tb - kTpBlock, lane);
                 // with the last block, the one -inf slot that stands for everything behind t_end (the tile above reads slots up to
                 // its own t_end - 1 = fill_end: none behind t_end when the two end together)
@@ -582,8 +588,8 @@ __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk
                 pairs += (uint32_t)lane * 8u;
                 asm volatile("" : "+v"(pairs));
                 {
-                    const uint32_t pk = lds_stage0 + (uint32_t)(it & 1) * kTpStageBytes;
-                    c.lds_stage = lane >= 62 ? pk + (uint32_t)(lane - 62) * 8u : pk + kTpBlock * 16 + (uint32_t)lane * 16u;
+                    const uint32_t pk = lds_stage0 + (uint32_t)(it & 1) * kStageBytes;
+                    c.lds_stage = lane >= 62 ? pk + (uint32_t)(lane - 62) * 8u : pk + kTpBlock * 16 + (uint32_t)lane * kScratch;
                 }
                 // the block's first four frames; the others are read four frames ahead (tg_frame)
                 TgIn in[4];
@@ -618,8 +624,8 @@ __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk
             asm volatile("" : "+v"(A[0].l0), "+v"(A[1].l0));
             // where this block's frames drop their packets: lane 63's into the packet row, the others' into scratch behind it
             {
-                const uint32_t pk = lds_stage0 + (uint32_t)(it & 1) * kTpStageBytes;
-                c.lds_stage = lane >= 62 ? pk + (uint32_t)(lane - 62) * 8u : pk + kTpBlock * 16 + (uint32_t)lane * 16u;
+                const uint32_t pk = lds_stage0 + (uint32_t)(it & 1) * kStageBytes;
+                c.lds_stage = lane >= 62 ? pk + (uint32_t)(lane - 62) * 8u : pk + kTpBlock * 16 + (uint32_t)lane * kScratch;
             }
             if (it == kb0) {
                 // the first four frames' rows and packets (later ones are read four frames ahead, tn_frame); slot t_in's packet
