@@ -1,14 +1,24 @@
-// ka_tiled_narrow.hpp — the two-wavefront tile pipeline of ka_tiled2.hpp with tiles of 128 positions: TWO cells per lane.
+// ka_tiled_narrow.hpp — the tile pipeline with tiles of 128 positions: TWO cells per lane, and up to three wavefronts per tile.
 //
 // Why: a wavefront that is alone on its SIMD does not issue a vector instruction every four cycles but every ~7 (timing
 // variants of the 256-position frame, DESIGN.md section 8: four more s_nop per frame cost 3.4 cycles each, four more
-// independent v_max 7.3 each), so a lone lattice's chain of tiles runs at the pace of the frame's instruction count.  With
-// two cells per lane a frame has one v_max for the blank, one v_max3 for the label, one v_pk_add_f32 and two or three DPP
+// independent v_max 7.3 each), so a lone lattice's chain of tiles runs at the pace of the frame's INSTRUCTION COUNT.  With
+// two cells per lane a frame has one v_max3 for the blank, a v_max and a v_max3 for the label, one v_pk_add_f32 and three DPP
 // moves, where the 256-position frame has twice the maxima and adds.  The price: twice as many tiles in the chain, i.e.
-// twice the hand-off lag (about three blocks per tile) and twice the workgroups - which is why this form is for launches
-// whose tiles all fit the chip at once.  Everything around the frame - feeder wavefront, staging, hand-off protocol,
-// checkpoints (position p of row r at r * ck_pitch + (p & ck_mask) * 4 whatever the
-// tile width) - is ka_tiled2.hpp's; the host plans the tiles with the same formulas for 128 positions.
+// twice the hand-offs and twice the workgroups - which is why the engine uses this form only while the launch's tiles (almost)
+// fit the device at once (ka_engine.hip: narrow_tiles_pay).
+//
+// Two forms:
+//   GATHER = true (the default): three wavefronts per tile.  The look-up wavefront turns the staged rows into per-lane
+//     emission pairs with the band's kills folded in as -inf; the compute wavefront's frame is 11 instructions with no band
+//     code; the feeder keeps the memory protocol.  See the GATHER block below.
+//   GATHER = false: two wavefronts as in ka_tiled2.hpp; the compute wavefront reads the staged rows itself and visits the band
+//     code (frame of 14 instructions).  Behind ka_debug_set_tile_gather(engine, 0).
+// Common to both, and different from ka_tiled2.hpp: the frame loop's LDS instructions are inline asm with hand-counted waits
+// (below), the feeder announces a block BEFORE it polls the tile below, and the slots behind the lower tile's t_end are one
+// -inf slot (TileTask::below_end) instead of a fill after the loop.  Staging, sc1 packets + progress words, checkpoints
+// (position p of row r at r * ck_pitch + (p & ck_mask) * 4 whatever the tile width) are ka_tiled2.hpp's; the host plans the
+// tiles with the same formulas for 128 positions.
 #pragma once
 #include "ka_tiled2.hpp"
 
