@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 T, V, S, BEAM, MAX_MOVE = 50000, 64, 5000, 1000, 4
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
-CK_FRAMES = 32          # kokoro-align_amd/csrc/ka_kernels.hpp kCkFrames: frames between stored score rings
+CK_FRAMES = 32          # kokoro-align_amd/csrc/ka_types.hpp kCkFrames: frames between stored score rings
 N_SIMD = 1024           # 256 CUs x 4
 
 
@@ -381,7 +381,7 @@ def main():
                     help="cfg2 workload: lattices per GPU per step")
     ap.add_argument("--streams", type=int, default=None,
                     help="launches in flight per GPU (cfg2: default 4 sub-batches on 4 engines / streams; book, corpus: 1)")
-    ap.add_argument("--mode", default="auto", choices=["auto", "wave", "wave_exact", "workgroup", "tiled"],
+    ap.add_argument("--mode", default="auto", choices=["auto", "wave", "wave_exact", "tiled"],
                     help="kernel form (DESIGN.md section 4); auto = one wavefront per lattice, checkpointed, at this batch size")
     ap.add_argument("--backtrace", default="auto", choices=["auto", "serial", "parallel"])
     ap.add_argument("--cpu-baseline-seconds", type=float, default=8.0)
@@ -613,7 +613,7 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same batch size)" if traffic else None,
                 "kernel": {"auto": "forward_ck_kernel<4,false>", "wave": "forward_ck_kernel<4,false>", "tiled": "forward_tn_kernel<4> (128-position tiles) or forward_tp2_kernel<4> (256) by the number of tiles alive",
-                           "wave_exact": "forward_w16_kernel<4,false>", "workgroup": "forward_wg4_kernel<4,false>"}[args.mode],
+                           "wave_exact": "forward_w16_kernel<4,false>"}[args.mode],
                 "kernel_ms": fwd_s * 1e3, "launch_lattices": B,
                 "measured": ("serial pass after the timed region: one launch over all lattices, alone on the GPU (HIP events on its stream)" if G > 1
                              else "HIP events on the launch stream inside the timed region"),

@@ -122,9 +122,7 @@ int ka_batch_finish(ka_engine *e, float *total_score, int32_t *status);
  *                       not all finite are redone by the exact kernels in the same call; a call with a lattice of
  *                       2^26 frames or more runs entirely in the exact form.
  *   KA_MODE_WAVE_EXACT  one wavefront per lattice, every back-pointer stored (2 bits per band cell).
- *   KA_MODE_WORKGROUP   four wavefronts per lattice with an LDS hand-off per frame; back-pointers stored.  The
- *                       shortest forward pass for one lattice, but WAVE's two kernels together are faster.
- *   KA_MODE_TILED       one wavefront per 256-position TILE of the label axis, the tiles of a lattice run as a pipeline
+ *   KA_MODE_TILED       a workgroup of two or three wavefronts per 256- or 128-position TILE of the label axis, the tiles of a lattice run as a pipeline
  *                       (scores only, checkpoints as WAVE): a lone lattice or a book's few dozen chapters, and ANY band
  *                       width (beam_size >= 2L is the reference's unbanded DP).  Non-finite log-probs: bands up to 1009 are
  *                       redone by the exact kernels, wider ones return KA_ERR_NONFINITE in this explicit mode.
@@ -135,7 +133,7 @@ int ka_batch_finish(ka_engine *e, float *total_score, int32_t *status);
  * Results are identical in every form. */
 #define KA_MODE_AUTO 0
 #define KA_MODE_WAVE 1
-#define KA_MODE_WORKGROUP 2
+/* (2 was KA_MODE_WORKGROUP, four wavefronts per lattice: superseded by the tiled form in round 2, removed in round 4) */
 #define KA_MODE_WAVE_EXACT 3
 #define KA_MODE_TILED 4
 int ka_engine_set_mode(ka_engine *e, int32_t mode);
@@ -184,9 +182,6 @@ int ka_debug_tile_width_choice(const int64_t *T, const int64_t *S, int32_t n, in
  * launches that fill the chip; by the counters 17 % more HBM traffic per step), 0 or -1 (default) = collected by the walk in
  * registers.  Results are identical. */
 int ka_debug_set_rc_gather(ka_engine *e, int32_t how);
-/* Wavefronts per tile of the tiled form: 2 (default; ka_tiled2.hpp: one wavefront runs the frames, the other stages rows and
- * halo packets, polls, publishes) or 1 (ka_tiled.hpp: one wavefront does both).  Results are identical. */
-int ka_engine_set_tile_waves(ka_engine *e, int32_t waves);
 /* Self-checks of the tiled form's hand-off, a combination of:
  *   1  the halo region is filled with a NaN sentinel before the launch and every packet a tile consumes is checked
  *      against it: a packet read before it was written gives the lattice KA_ERR_INTERNAL (tests)

@@ -33,7 +33,7 @@ EXPORTS = [
     "ka_hash_logprobs_batch_f32", "ka_hash_labels_batch_i32", "ka_engine_set_mode", "ka_lstm_step_f32",
     "ka_lstm_layer_f32", "ka_window_energy_f32", "ka_stft_frames_f32", "ka_power_f32", "ka_power_to_db_f32",
     "ka_debug_tile_stats", "ka_engine_set_backtrace", "ka_debug_chunk_entries", "ka_debug_plan_tiles",
-    "ka_engine_set_verify", "ka_stream_create", "ka_stream_destroy", "ka_engine_set_tile_waves",
+    "ka_engine_set_verify", "ka_stream_create", "ka_stream_destroy",
     "ka_debug_set_split", "ka_engine_workspace_bytes", "ka_debug_set_tile_lds",
     "ka_debug_auto_split", "ka_debug_set_rc_gather", "ka_lstm_layer0_f32", "ka_debug_set_tile_width", "ka_debug_set_tile_gather", "ka_debug_tile_width_choice", "ka_debug_plan_tiles_width",
 ]
@@ -49,7 +49,9 @@ def library_path():
 
 def build_library(force=False):
     """Compile the HIP library for gfx950 (cross-compiles without a GPU)."""
-    srcs = [os.path.join(_PKG, "csrc", f) for f in ("ka_engine.hip", "ka_kernels.hpp", "ka_tiled.hpp", "ka_tiled2.hpp", "ka_parallel_bt.hpp")]
+    # every source of the library (a hand-kept list once missed the header of the default tiled kernel: a stale .so was tested)
+    csrc = os.path.join(_PKG, "csrc")
+    srcs = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".hpp", ".h", ".cpp")) or f == "Makefile"]
     srcs.append(os.path.join(os.path.dirname(_PKG), "include", "kokoro_align_amd.h"))
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:
@@ -116,8 +118,6 @@ def load_library():
     L.ka_debug_set_tile_width.argtypes = [vp, i32]
     L.ka_debug_set_split.restype = ctypes.c_int
     L.ka_debug_set_split.argtypes = [vp, i32, i32]
-    L.ka_engine_set_tile_waves.restype = ctypes.c_int
-    L.ka_engine_set_tile_waves.argtypes = [vp, i32]
     L.ka_engine_set_verify.restype = ctypes.c_int
     L.ka_engine_set_verify.argtypes = [vp, i32]
     L.ka_engine_set_profiling.restype = ctypes.c_int
@@ -208,10 +208,10 @@ class Engine:
             pass
 
     def set_mode(self, mode):
-        """'auto' | 'wave' (1 wavefront per lattice, checkpointed) | 'workgroup' (4 wavefronts per lattice) |
-        'wave_exact' (1 wavefront per lattice, every back-pointer stored) | 'tiled' (a pipeline of 256-position tiles,
-        one wavefront each: few lattices, any band width)"""
-        code = {"auto": 0, "wave": 1, "workgroup": 2, "wave_exact": 3, "tiled": 4}[mode] if isinstance(mode, str) else int(mode)
+        """'auto' | 'wave' (1 wavefront per lattice, checkpointed) | 'wave_exact' (1 wavefront per lattice, every back-pointer
+        stored) | 'tiled' (a pipeline of 128- or 256-position tiles, a workgroup of two or three wavefronts each: few lattices,
+        any band width)"""
+        code = {"auto": 0, "wave": 1, "wave_exact": 3, "tiled": 4}[mode] if isinstance(mode, str) else int(mode)
         check(self.lib.ka_engine_set_mode(self.handle, code), "ka_engine_set_mode")
 
     def set_backtrace(self, how):
@@ -237,10 +237,6 @@ class Engine:
     def set_tile_gather(self, how):
         """128-position tiles: the feeder looks up the emissions (1), the compute wavefront does (0), -1 = the library's choice."""
         check(self.lib.ka_debug_set_tile_gather(self.handle, int(how)), "ka_debug_set_tile_gather")
-
-    def set_tile_waves(self, waves):
-        """Wavefronts per tile of the tiled form: 2 (default: one computes, one feeds) or 1."""
-        check(self.lib.ka_engine_set_tile_waves(self.handle, int(waves)), "ka_engine_set_tile_waves")
 
     def set_verify(self, flags):
         """Self-checks of the tiled form's hand-off (ka_engine_set_verify): 1 = sentinel-filled halos, every consumed packet

@@ -19,16 +19,10 @@
 // Bit-exact by construction: the maps are made of the same float operations, in the same order, as the forward kernels and
 // the reference; the parity suite runs in this form too (KA_MODE_* x parallel backtrace).
 #pragma once
-#include "ka_kernels.hpp"
+#include "ka_device.hpp"
 
 namespace ka {
 
-constexpr int kCmCells = 8;                      // cells per lane
-constexpr int kCmSpan = 64 * kCmCells;           // positions a wavefront recomputes
-constexpr int kCmWarm = 96;                      // lowest positions of the window: warm-up only (3 positions x 32 frames)
-constexpr int kCmOut = 408;                      // positions a wavefront delivers (a multiple of 8, <= kCmSpan - kCmWarm - 7)
-constexpr int kSuperChunks = 32;                 // chunks per super-chunk
-static_assert(kCmWarm == 3 * kCkFrames && kCmOut % 8 == 0 && kCmOut + kCmWarm <= kCmSpan, "window geometry");
 
 __device__ __forceinline__ int supers_of(int n_chunks) { return (n_chunks + kSuperChunks - 1) / kSuperChunks; }
 __device__ __forceinline__ int chunk_last_frame(int c, int T) { return min(c * kCkFrames + kCkFrames - 1, T - 1); }

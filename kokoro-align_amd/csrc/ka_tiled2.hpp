@@ -23,8 +23,6 @@
 
 namespace ka {
 
-constexpr int kTp2BandBytes = 64 * 8 + 16;           // per block: KL, KE of 64 lanes + the event mask (worked out by the feeder, tp_band_block)
-constexpr int kTp2StageBytes = 2 * kTpStageBytes;   // publish staging, double-buffered (the feeder reads block it-1's while block it's is written)
 
 // the barrier of an iteration: each side first finishes what the other is going to look at (the compute wavefront its LDS
 // writes; the feeder has already waited for its LDS-DMA with a counted vmcnt) - NOT the vmcnt(0) of __syncthreads, which

@@ -24,8 +24,6 @@
 
 namespace ka {
 
-constexpr int kTnCells = 2;
-constexpr int kTnTile = 64 * kTnCells;
 
 template <int M, bool ZL>
 struct TnTile {
@@ -211,21 +209,6 @@ __device__ __forceinline__ void tn_block_frames(TnTile<M, ZL> &c, uint32_t tb, f
 // LDS: 2 x 16 KB of pairs; the compute wavefront no longer reads rows, so two row slots do (the block being looked up and
 // the one landing), and two packet slots - 46.1 KB per workgroup for V = 39, 52.1 KB for V = 64: three per CU.
 // ---------------------------------------------------------------------------------------
-constexpr int kTgPairBytes = kTpBlock * 64 * 8;
-template <int PITCH, bool CONTIG, bool GATHER>
-struct TnLds {
-    static constexpr int kRowDmas = !CONTIG ? kTpBlock : (kTpBlock * PITCH + 1023) / 1024;
-    static constexpr int kRing = GATHER ? 2 : kTpRing;                                        // row slots
-    static constexpr int kSlot = GATHER && CONTIG ? kRowDmas * 1024 : kTpSlotBytes;           // bytes per row slot
-    static constexpr int kPkRing = GATHER ? 2 : kTpRing;                                      // packet slots (GATHER: the block being read, the one landing)
-    static constexpr int kStageBytes = GATHER ? 1536 : kTpStageBytes;                         // a publish staging buffer (GATHER: the idle lanes' scratch 8 bytes apart)
-    static constexpr int kHalo = kRing * kSlot;                                               // packets of the tile below: kPkRing slots of 32
-    static constexpr int kPoll = kHalo + kPkRing * kTpBlock * 16;
-    static constexpr int kStage = kPoll + 16;
-    static constexpr int kStat = kStage + 2 * kStageBytes;                                     // 12 diagnostic words, the ticket at +48
-    static constexpr int kBand = kStat + 64;                                                  // !GATHER: two band buffers;  GATHER: two pair buffers
-    static constexpr int kTotal = kBand + (GATHER ? 2 * kTgPairBytes : 2 * kTp2BandBytes);
-};
 static_assert(TnLds<256, true, false>::kTotal <= (int)kTpLdsRequest, "LDS budget of the narrow tile");
 static_assert(3 * ((TnLds<256, true, true>::kTotal + 511) / 512 * 512) <= 160 * 1024 && 3 * ((TnLds<256, false, true>::kTotal + 511) / 512 * 512) <= 160 * 1024,
               "three look-up workgroups per CU");

@@ -273,7 +273,7 @@ def _swap_ext(files, old, new):
 
 def process_alignment_sharded(dataset, audio_files, metadata_file, model=None, remove_wordsep=False, device=None,
                               host_softmax=False, verbose=True, rank=None, world_size=None, barrier=None,
-                              best_path_files_fn=None):
+                              best_path_files_fn=None, any_rank=None):
     """process_alignment for one dataset over the ranks of a node: one process per GPU (torch.distributed, RCCL);
     BASELINE.json configs[3] ("Meian sharded across 8 GPUs").
 
@@ -285,7 +285,9 @@ def process_alignment_sharded(dataset, audio_files, metadata_file, model=None, r
     `*.align.txt` into the metadata file (run_example.py:273-278).  The model is assumed to be on every rank already
     (sharding.broadcast_model_weights at start-up).  `rank` / `world_size` / `barrier` default to torch.distributed's;
     `best_path_files_fn` replaces the DP stage (the CPU tests put the oracle there: the product has no CPU path).
-    Returns the metadata file name on rank 0, None elsewhere."""
+    `any_rank(flag) -> bool` tells every rank whether ANY rank raised the flag (default: an all-reduce MAX over
+    torch.distributed; it is also the second barrier): when one rank fails, every rank raises and rank 0 does not merge
+    files the failed rank never wrote.  Returns the metadata file name on rank 0, None elsewhere."""
     from .sharding import shard_for_rank
     from .transcript import read_transcript
     if rank is None or world_size is None:
@@ -293,13 +295,20 @@ def process_alignment_sharded(dataset, audio_files, metadata_file, model=None, r
         rank, world_size = dist.get_rank(), dist.get_world_size()
         if barrier is None:
             barrier = dist.barrier
+        if any_rank is None:
+            def any_rank(flag):
+                import torch
+                dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+                t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return bool(int(t.item()))
     # The split_audio stage first, files dealt round-robin (its outputs size the shards below): a dataset whose MFCCs have not
     # been made yet goes through the same stage process_alignment would run, instead of failing on a missing file.
     failure = None
     try:
         for af in audio_files[rank::world_size]:
             _ensure_mfcc(af, print if verbose else (lambda *a, **k: None))
-    except BaseException as exc:       # every rank must reach the barrier: a rank that raised before it would hang the others
+    except Exception as exc:           # every rank must reach the barrier: a rank that raised before it would hang the others
         failure = exc
     if barrier is not None:
         barrier()
@@ -315,12 +324,19 @@ def process_alignment_sharded(dataset, audio_files, metadata_file, model=None, r
             if mine:
                 process_alignment(dataset, mine, None, model=model, remove_wordsep=remove_wordsep, device=device,
                                   host_softmax=host_softmax, verbose=verbose, best_path_files_fn=best_path_files_fn)
-        except BaseException as exc:
+        except Exception as exc:
             failure = exc
-    if barrier is not None:
-        barrier()
+    # the failure is shared: the other ranks must not report success, and rank 0 must not merge a partial dataset
+    if any_rank is not None:
+        somebody_failed = any_rank(failure is not None)
+    else:
+        somebody_failed = failure is not None
+        if barrier is not None:
+            barrier()
     if failure is not None:
         raise failure
+    if somebody_failed:
+        raise RuntimeError(f"process_alignment_sharded({dataset}): another rank failed; {metadata_file} was not written")
     if rank != 0:
         return None
     say = print if verbose else (lambda *a, **k: None)

@@ -100,7 +100,10 @@ class StreamedAligner:
             try:
                 torch.cuda.set_device(self.device)
                 with torch.cuda.stream(self.streams[g]):
-                    gate.wait()
+                    try:
+                        gate.wait(timeout=120)
+                    except threading.BrokenBarrierError:
+                        return                # another worker failed before the start: its error is the one reported
                     if stagger_s:
                         time.sleep(g * stagger_s)
                     for _ in range(repeat):
@@ -114,15 +117,20 @@ class StreamedAligner:
             except BaseException as exc:      # re-raised in the caller's thread
                 with lock:
                     errors.append(exc)
+                gate.abort()                  # a worker that fails before the gate must not leave the others waiting at it
 
         threads = [threading.Thread(target=worker, args=(g,), name=f"ka-stream-{g}") for g in range(self.n_streams) if mine[g]]
         for t in threads:
             t.start()
-        gate.wait()
+        try:
+            gate.wait(timeout=120)
+        except threading.BrokenBarrierError:
+            pass
         for t in threads:
             t.join()
         if errors:
-            raise errors[0]
+            real = [x for x in errors if not isinstance(x, threading.BrokenBarrierError)]
+            raise (real or errors)[0]
         return [b.status for b in batches]
 
 

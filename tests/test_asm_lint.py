@@ -19,6 +19,8 @@ def test_no_copy_of_a_register_whose_load_is_in_flight():
     subprocess.run(["make", "-C", CSRC, "asm"], check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import lint_inflight
-    report, total = lint_inflight.check(os.path.join(CSRC, "ka_engine.s"))
+    paths = lint_inflight.default_paths()
+    assert len(paths) >= 6, "one assembly file per device translation unit"
+    report, total = lint_inflight.check_all(paths)
     assert len(report) >= 30, "kernels not found in the assembly"
     assert total == 0, [(n, f[:3]) for n, f in report if f]

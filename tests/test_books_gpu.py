@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 # "tiled/256", "tiled/128": the tile pipeline with the tile width forced (ka_tiled2.hpp / ka_tiled_narrow.hpp; plain "tiled" lets the
 # library choose by the number of tiles alive at once); "tiled/128n": 128 positions, the two-wavefront form whose compute
 # wavefront reads the staged rows itself (ka_debug_set_tile_gather(0))
-MODES = ["wave", "workgroup", "wave_exact", "tiled/256", "tiled/128", "tiled/128n", "wave+parallel", "tiled/256+parallel", "tiled/128+parallel", "auto"]
+MODES = ["wave", "wave_exact", "tiled/256", "tiled/128", "tiled/128n", "wave+parallel", "tiled/256+parallel", "tiled/128+parallel", "auto"]
 _oracle_cache = {}
 
 

@@ -13,7 +13,7 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["wave", "workgroup", "wave_exact", "tiled/256", "tiled/128", "tiled/128n", "wave+parallel", "tiled/256+parallel", "tiled/128+parallel"])
+@pytest.fixture(scope="module", params=["wave", "wave_exact", "tiled/256", "tiled/128", "tiled/128n", "wave+parallel", "tiled/256+parallel", "tiled/128+parallel"])
 def ka(request):
     """Every test runs in every kernel form: one wavefront per lattice checkpointed / exact,
     four wavefronts per lattice, the tile pipeline with tiles of 256 and of 128 positions - and the checkpointed forms once

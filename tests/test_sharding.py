@@ -170,3 +170,50 @@ def test_process_alignment_sharded_ws2_writes_what_one_process_writes(tmp_path):
             with np.load(a) as x, np.load(b) as y:
                 assert all(np.array_equal(x[k], y[k]) for k in ("best_path", "best_labels", "best_scores")), f
     assert open(os.path.join(one, "out", "ds.metadata.txt")).read() == open(os.path.join(two, "out", "ds.metadata.txt")).read()
+
+
+# ------------------------------------------------------------------------------------------
+# one rank fails: every rank raises, nobody hangs, rank 0 does not merge a partial dataset
+# ------------------------------------------------------------------------------------------
+def _failing_best_path_files(logits_files, voca_files, out_files, **kw):
+    if any(os.path.basename(f).startswith("rec4.") for f in logits_files):
+        raise OSError("rec4 cannot be aligned (injected)")
+    return _oracle_best_path_files(logits_files, voca_files, out_files, **kw)
+
+
+def _sharded_failing_worker(rank, world, port, root, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kokoro_align_amd import pipeline
+        audio = sorted(os.path.join(root, f) for f in os.listdir(root) if f.endswith(".voca.txt"))
+        audio = [a[:-len(".voca.txt")] + ".mp3" for a in audio]
+        try:
+            pipeline.process_alignment_sharded("ds", audio, os.path.join(root, "out", "ds.metadata.txt"), verbose=False,
+                                               best_path_files_fn=_failing_best_path_files)
+            q.put((rank, "returned"))
+        except OSError as exc:
+            q.put((rank, "own:" + str(exc)))
+        except RuntimeError as exc:
+            q.put((rank, "other:" + str(exc)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_process_alignment_sharded_ws2_one_rank_fails_every_rank_raises(tmp_path):
+    root = str(tmp_path / "ds")
+    os.makedirs(root)
+    _make_dataset(root)
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_failing_worker, args=(r, world, port, root, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    kinds = sorted(v.split(":")[0] for v in res.values())
+    assert kinds == ["other", "own"], res          # the owner of rec4 re-raises its error, the other rank learns of it
+    assert not os.path.exists(os.path.join(root, "out", "ds.metadata.txt"))

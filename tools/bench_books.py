@@ -40,7 +40,7 @@ def run(name, shapes):
     frames = sum(t for t, _ in shapes)
     out = {"book": name, "chapters": len(shapes), "frames": frames, "longest_chapter": max(t for t, _ in shapes)}
     ref = None
-    for mode in ("workgroup", "wave"):
+    for mode in ("wave_exact", "wave"):
         b = DeviceBatch(lps, labs)
         b.engine.set_mode(mode)
         b.run()

@@ -16,13 +16,13 @@ b = DeviceBatch(lps, labs)
 e = b.engine
 e.set_tile_width(int(os.environ.get("KA_TILE_WIDTH", "0")))     # 0: the library chooses; 128 / 256 forced
 e.set_tile_gather(int(os.environ.get("KA_TILE_GATHER", "-1")))
-def run(mode, bt, waves, split=(-1, -1)):
-    e.set_mode(mode); e.set_backtrace(bt); e.set_tile_waves(waves); e.set_split(*split)
+def run(mode, bt, split=(-1, -1)):
+    e.set_mode(mode); e.set_backtrace(bt); e.set_split(*split)
     st = b.run(raise_on_error=False)
     return [p.clone() for p in b.path], b.total.copy(), st.copy()
-ref, rt, _ = run("wave", "serial", 2)
+ref, rt, _ = run("wave", "serial")
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-for cfg in [("tiled", "serial", 2)] * reps + [("tiled", "parallel", 2), ("tiled", "serial", 1), ("auto", "auto", 2, (len(shapes), 0)), ("auto", "auto", 2)]:
+for cfg in [("tiled", "serial")] * reps + [("tiled", "parallel"), ("auto", "auto", (len(shapes), 0)), ("auto", "auto")]:
     p, t, st = run(*cfg)
     bad = [i for i in range(len(shapes)) if not torch.equal(ref[i], p[i])]
     badt = [i for i in range(len(shapes)) if np.float32(rt[i]).view(np.int32) != np.float32(t[i]).view(np.int32)]

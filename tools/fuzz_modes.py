@@ -24,7 +24,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 # (mode, backtrace, positions per tile: 0 = the library's choice, 128-position tiles: who looks up the emissions: -1 = the library's choice)
 FORMS = [("auto", "auto", 0, -1), ("tiled", "parallel", 256, -1), ("tiled", "serial", 256, -1), ("tiled", "parallel", 128, 0), ("tiled", "serial", 128, 1),
-         ("wave", "serial", 0, -1), ("wave", "parallel", 0, -1), ("wave_exact", "auto", 0, -1), ("workgroup", "auto", 0, -1)]
+         ("wave", "serial", 0, -1), ("wave", "parallel", 0, -1), ("wave_exact", "auto", 0, -1)]
 eng = _lib.default_engine(0)
 t_end = time.time() + budget
 n_cases = n_lattices = 0

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static check of the compiled kernels (ka_engine.s from `make -C kokoro-align_amd/csrc asm`).
+"""Static check of the compiled kernels (kokoro-align_amd/csrc/build/*.s from `make -C kokoro-align_amd/csrc asm`).
 
 The forward / backtrace kernels issue their prefetch loads from inline asm and release the destination
 registers with counted s_waitcnt statements.  hipcc does not know those registers are in flight: if its
@@ -27,13 +27,13 @@ must not write them.  The compiler honours that for its own stores; behind an in
 refills a staging register in the very next instruction (first seen as checkpoints whose first dword came from
 the next group, only under load).
 
-    python tools/lint_inflight.py [path/to/ka_engine.s]      exit status 1 when something is reported
+    python tools/lint_inflight.py [file.s ...]      (default: every build/*.s)  exit status 1 when something is reported
 """
 import os
 import re
 import sys
 
-KERNELS = ("forward_ck", "forward_w16", "forward_wg4", "backtrace_rc", "backtrace_w16", "forward_tp", "forward_tn", "chunk_map")
+KERNELS = ("forward_ck", "forward_w16", "backtrace_rc", "backtrace_w16", "forward_tp", "forward_tn", "chunk_map")
 VMEM = re.compile(r"\s*(global_load|global_store|buffer_load|buffer_store|flat_load|flat_store|global_atomic)\w*\s+(.*)")
 WAIT = re.compile(r"\s*s_waitcnt\s+(.*)")
 MOV = re.compile(r"\s*v_mov_b32(?:_e32|_dpp|_e64)?\s+(v[0-9]+),\s*(v[0-9]+)\b")
@@ -191,10 +191,25 @@ def check(path):
     return report, total
 
 
+def default_paths():
+    import glob
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return sorted(glob.glob(os.path.join(here, "kokoro-align_amd", "csrc", "build", "*.s")))
+
+
+def check_all(paths):
+    report, total = [], 0
+    for p in paths:
+        r, t = check(p)
+        report += r
+        total += t
+    return report, total
+
+
 if __name__ == "__main__":
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "kokoro-align_amd", "csrc", "ka_engine.s")
-    rep, total = check(path)
+    paths = sys.argv[1:] or default_paths()
+    rep, total = check_all(paths)
     for name, found in rep:
         if found:
             print(f"{name}: {len(found)} hazards (copy of a register whose load may be in flight / write of a wide store's data), e.g. {found[:3]}")

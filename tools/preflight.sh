@@ -5,5 +5,5 @@ set -e
 cd "$(dirname "$0")/.."
 out=$(make -C kokoro-align_amd/csrc 2>&1) || { echo "$out" | grep -E "error" | head -20; echo "BUILD FAILED"; exit 1; }
 make -C kokoro-align_amd/csrc asm >/dev/null 2>&1 || { echo "ASM BUILD FAILED"; exit 1; }
-python tools/lint_inflight.py kokoro-align_amd/csrc/ka_engine.s | tail -2
-python tools/lint_inflight.py kokoro-align_amd/csrc/ka_engine.s >/dev/null
+python tools/lint_inflight.py | tail -2
+python tools/lint_inflight.py >/dev/null
