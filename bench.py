@@ -202,6 +202,7 @@ def timed_batch(batch, reps):
 def latency_entries(lps0, labs0):
     """The few-lattice regime (rank 0, N=1): a lone cfg2 lattice and the two book stand-ins, library defaults
     (KA_MODE_AUTO: tile pipeline + chunk-parallel backtrace) next to the one-wavefront form with the serial backtrace."""
+    import numpy as np
     import torch
     from kokoro_align_amd import workloads as W
     from kokoro_align_amd.align import DeviceBatch
@@ -234,6 +235,26 @@ def latency_entries(lps0, labs0):
     one.engine.set_mode("auto")
     one.engine.set_backtrace("auto")
     out["book"] = books
+    # BASELINE.json configs[0] (one recording of the reference's CPU case: 81 140 frames x 39 classes, S = 2000) and configs[4]
+    # (the long-form stress lattice T = 500 000, S = 50 000: with the reference's band of 1000 and as the whole lattice,
+    # beam_size >= 2L = the "tiled DP"), one lattice each under the library defaults.  Checked on the spot: the path ends at the
+    # trailing blank, rises by at most 3 per frame, and the float32 chain of its scores equals the forward pass's total bit for bit.
+    for key, cfg, V, seed, beam in (("cfg1", W.CFG1, W.V_MODEL, 77, BEAM), ("cfg5_band", W.CFG5, 64, 5, BEAM),
+                                    ("cfg5_whole_lattice", W.CFG5, 64, 5, 2 * (2 * W.CFG5["S"] + 1))):
+        Tk, Sk = cfg["T"], cfg["S"]
+        lps, labs = W.device_book([(Tk, Sk)], V=V, seed0=seed)
+        b = DeviceBatch(lps, labs, beam, MAX_MOVE)
+        b.engine.set_profiling(True)
+        dt, k = timed_batch(b, 2)
+        path = b.path[0].cpu().numpy()
+        steps = np.diff(path)
+        out[key] = {"ms": dt * 1e3, "frames_per_s": Tk / dt, "forward_ms": k["forward"], "backtrace_ms": k["backtrace"],
+                    "workload": f"T={Tk} x V={V}, S={Sk} (L={2 * Sk + 1}), beam_size={beam}", "cells": int(Tk) * int(min(beam, 2 * Sk + 1)),
+                    "ends_at_trailing_blank": bool(int(path[-1]) == 2 * Sk), "steps_within_0_3": bool(steps.min() >= 0 and steps.max() <= 3),
+                    "score_chain_equals_total": bool(np_chain(b.best_scores[0]) == np_bits(b.total[0]))}
+        b.engine.set_profiling(False)
+        del lps, labs, b
+        torch.cuda.empty_cache()
     return out
 
 

@@ -19,6 +19,9 @@ Fixtures
                      texts + lines that hit every blocking rule; AudioToChar (hidden 8) weights,
                      packed 3-segment input and logits (train.py:54-65, :92-95)
 
+  g7_audio_to_char_default.npz   the reference's AudioToChar at DEFAULT_PARAMS (hidden 128): seeded weights, 19 ragged
+                     segments, logits (train.py:16-20, :54-65, :92-95) - pins the persistent LSTM kernel
+
 Reference entry points exercised: kokoro_align/align.py:43 (ctc_best_path), :112 (best_path),
 :127 (align); kokoro_align/encoder.py:14-31; kokoro_align/transcript.py:13-67.
 
@@ -426,7 +429,42 @@ def make_g6():
     print("g6: written;", [(c["name"][:20], c["status"], len(c.get("split_points", []))) for c in cases])
 
 
+def make_g7():
+    """The reference's AudioToChar at its DEFAULT_PARAMS (train.py:16-20: n_mfcc 40, hidden_dim 128, vocab 39 - the size the
+    persistent HIP kernel ka_lstm_layer_f32 is built for), weights from the reference's own initialisation under a fixed
+    seed, ragged segments (lengths 1 .. 300, one longer than a 16-sequence tile's neighbours) packed by the reference's
+    generate_batch_audio (train.py:92-95) and run through its forward (train.py:61-65).  Stored: the weights (float32, so that
+    a different initialisation stream in another torch build is seen rather than silently compared), their SHA-256, the
+    recipe of the inputs (hash generator) and the logits of every segment."""
+    import torch
+    from kokoro_align import train as rtrain
+
+    torch.manual_seed(4321)
+    model = rtrain.AudioToChar(**rtrain.DEFAULT_PARAMS).eval()
+    state = {k: v.numpy().astype(np.float32) for k, v in model.state_dict().items()}
+    lens = [1, 7, 129, 300, 64, 2, 33, 18, 257, 96, 5, 41, 300, 17, 150, 3, 80, 222, 9]     # 19 segments: two tiles of 16
+    seeds = [7000 + i for i in range(len(lens))]
+    segs = [np.ascontiguousarray(hash_logprobs(n, 40, sd) * np.float32(0.75) + np.float32(3.0)) for n, sd in zip(lens, seeds)]
+    with torch.no_grad():
+        packed = rtrain.generate_batch_audio([torch.from_numpy(x) for x in segs])
+        logits, out_lens = model(packed)
+    assert out_lens.tolist() == lens
+    h = hashlib.sha256()
+    for k in sorted(state):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(state[k]).tobytes())
+    arrays = {"w:" + k: v for k, v in state.items()}
+    arrays["segment_lens"] = np.array(lens, np.int32)
+    arrays["segment_seeds"] = np.array(seeds, np.int32)
+    arrays["input_scale_offset"] = np.array([0.75, 3.0], np.float32)
+    arrays["logits"] = np.concatenate([logits[:n, j, :].numpy() for j, n in enumerate(lens)], 0).astype(np.float32)
+    arrays["state_sha256"] = np.frombuffer(h.hexdigest().encode(), dtype=np.uint8)
+    arrays["params"] = np.array([rtrain.DEFAULT_PARAMS["n_mfcc"], rtrain.DEFAULT_PARAMS["hidden_dim"], rtrain.DEFAULT_PARAMS["vocab_size"]], np.int32)
+    np.savez_compressed(os.path.join(HERE, "g7_audio_to_char_default.npz"), **arrays)
+    print("g7: written;", len(lens), "segments,", int(sum(lens)), "frames,", sum(v.size for v in state.values()), "weights, sha", h.hexdigest()[:16])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
     for w in which:
-        {"g1": make_g1, "g2": make_g2, "g3": make_g3, "g4": make_g4, "g5": make_g5, "g6": make_g6}[w]()
+        {"g1": make_g1, "g2": make_g2, "g3": make_g3, "g4": make_g4, "g5": make_g5, "g6": make_g6, "g7": make_g7}[w]()

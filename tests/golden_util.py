@@ -69,3 +69,26 @@ def g6():
     """Silence-splitting goldens (reference get_split_points / get_silent_ranges on synthetic recordings)."""
     with open(os.path.join(GOLDEN, "g6_split.json")) as f:
         return json.load(f)
+
+
+def g7():
+    """The reference's AudioToChar at DEFAULT_PARAMS: dict with `state` (name -> float32 array), `lens`, `seeds`, `scale`,
+    `offset`, `logits` (list of [len_i, 39]) and `sha` (of the stored weights, recomputed here: a damaged file is seen)."""
+    with np.load(os.path.join(GOLDEN, "g7_audio_to_char_default.npz")) as f:
+        state = {k[2:]: f[k] for k in f.files if k.startswith("w:")}
+        lens = f["segment_lens"].tolist()
+        seeds = f["segment_seeds"].tolist()
+        scale, offset = (float(x) for x in f["input_scale_offset"])
+        flat = f["logits"]
+        sha_stored = bytes(f["state_sha256"]).decode()
+        params = f["params"].tolist()
+    h = hashlib.sha256()
+    for k in sorted(state):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(state[k]).tobytes())
+    assert h.hexdigest() == sha_stored, "g7: stored weights do not match their checksum"
+    logits, k = [], 0
+    for n in lens:
+        logits.append(flat[k:k + n])
+        k += n
+    return dict(state=state, lens=lens, seeds=seeds, scale=scale, offset=offset, logits=logits, sha=sha_stored, params=params)

@@ -77,3 +77,22 @@ def test_index_data_array_format(tmp_path):
             w.write(parts[0])
             raise RuntimeError("producer failed")
     assert not os.path.exists(g)          # nothing written on failure (preprocess.py:27)
+
+
+def test_mirror_network_reproduces_the_reference_at_default_params():
+    """g7: the reference's AudioToChar(**DEFAULT_PARAMS) (train.py:16-20, :54-65) - our mirror module with the stored weights gives
+    the stored logits on the CPU (same PyTorch LSTM arithmetic), so the GPU test of the persistent kernel compares against
+    numbers the reference produced, not against this repository's own network."""
+    import numpy as np
+    import torch
+    from golden_util import g7
+    from oracle import oracle as O
+    from kokoro_align_amd.model import AudioToChar, DEFAULT_PARAMS, segment_logits
+    g = g7()
+    assert g["params"] == [DEFAULT_PARAMS["n_mfcc"], DEFAULT_PARAMS["hidden_dim"], DEFAULT_PARAMS["vocab_size"]] == [40, 128, 39]
+    model = AudioToChar().eval()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in g["state"].items()})
+    segs = [O.hash_logprobs(n, 40, sd) * np.float32(g["scale"]) + np.float32(g["offset"]) for n, sd in zip(g["lens"], g["seeds"])]
+    got = segment_logits(model, segs, device="cpu")
+    for a, w in zip(got, g["logits"]):
+        np.testing.assert_allclose(a.numpy(), w, rtol=0, atol=1e-5)

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from golden_util import g4, g5
+from golden_util import g4, g5, g7
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -26,6 +26,30 @@ def test_audio_to_char_on_gpu_matches_reference(tmp_path):
         for g, w in zip(got, a["logits"]):
             assert g.is_cuda
             assert np.allclose(g.cpu().numpy(), np.array(w, np.float32), atol=1e-4, rtol=0)
+
+
+def test_persistent_lstm_kernel_matches_the_reference_at_default_params():
+    """g7 (reference-made: AudioToChar(**DEFAULT_PARAMS), train.py:16-20, :54-65, :92-95; 19 ragged segments of 1..300 frames =
+    two 16-sequence tiles): the hand-written MFMA kernel ka_lstm_layer_f32 / ka_lstm_layer0_f32 - what the pipeline runs - against
+    the logits the reference computed.  North-star tolerance 1e-4."""
+    import torch
+    from kokoro_align_amd.model import AudioToChar, lstm_logits_device, segment_logits_device
+    g = g7()
+    model = AudioToChar()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in g["state"].items()})
+    model = model.cuda().eval()
+    assert model.hidden_dim == 128            # the size that takes the persistent path (model.py: persistent and H == 128)
+    segs = [O.hash_logprobs(n, 40, sd) * np.float32(g["scale"]) + np.float32(g["offset"]) for n, sd in zip(g["lens"], g["seeds"])]
+    worst = {}
+    for name, kw in (("persistent, layer-0 projection inside", dict(persistent=True)), ("per step", dict(persistent=False))):
+        got = segment_logits_device(model, segs, **kw)
+        assert len(got) == len(g["logits"])
+        worst[name] = max(float(np.max(np.abs(a.cpu().numpy() - w))) for a, w in zip(got, g["logits"]))
+    # ... and with the layer-0 projection as a library GEMM in front of the persistent kernel
+    data = np.concatenate(segs, 0)
+    c = lstm_logits_device(model, data, np.cumsum(g["lens"]), persistent=True, fuse_layer0=False).cpu().numpy()
+    worst["persistent, projection as a GEMM"] = float(np.max(np.abs(c - np.concatenate(g["logits"], 0))))
+    assert all(v <= 1e-4 for v in worst.values()), worst
 
 
 def test_process_alignment_end_to_end(tmp_path):
