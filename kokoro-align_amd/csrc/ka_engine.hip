@@ -842,6 +842,8 @@ int ka_debug_tile_stats(ka_engine *e, uint64_t *out, int32_t max_tasks)
         if ((e->verify & 4) && (i == 0 || i == 10 || i == 20)) std::fprintf(stderr, "[ka_debug_tile_stats] ticket %zu cycles per phase: wait %llu, check+sum %llu, progress %llu, requests %llu, publish %llu\n", i,
                                  (unsigned long long)(uint32_t)st[i].phase[0], (unsigned long long)(st[i].phase[0] >> 32), (unsigned long long)(uint32_t)st[i].phase[1],
                                  (unsigned long long)(st[i].phase[1] >> 32), (unsigned long long)(uint32_t)st[i].phase[2]);
+        if ((e->verify & 4) && (i == 0 || i == 10 || i == 20) && st[i].extra[0]) std::fprintf(stderr, "[ka_debug_tile_stats] ticket %zu compute wavefront: %llu cycles in frame blocks, %llu at barriers; look-up wavefront busy %llu\n", i,
+                                 (unsigned long long)(st[i].extra[0] >> 32), (unsigned long long)(uint32_t)st[i].extra[0], (unsigned long long)st[i].extra[1]);
     }
     return (int)n;
 }

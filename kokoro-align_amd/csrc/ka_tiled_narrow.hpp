@@ -509,7 +509,12 @@ __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk
     // Iterations kb0-2, kb0-1 prime the feeder's pipeline; iteration kb1+1 publishes the last block.
     for (int32_t it = kb0 - 2; it <= kb1 + 1; ++it) {
         const uint32_t tb = (uint32_t)(it * kTpBlock);              // (wraps in the priming iterations of block 0: not used there)
-        tp2_barrier();
+        if ((verify & 4) && role == 0) {        // ka_engine_set_verify(4): how long the compute wavefront stands at the barrier
+            const unsigned long long b0 = __builtin_amdgcn_s_memtime();
+            tp2_barrier();
+            ((lu32_t)(uintptr_t)stat_lds)[8] += (uint32_t)(__builtin_amdgcn_s_memtime() - b0);
+        } else
+            tp2_barrier();
         if (feeder) {
             phase(-1);
             // What the tile above is waiting for comes first: block it-1 is complete in staging buffer (it-1) & 1 - lane f < 32
@@ -572,8 +577,10 @@ __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             phase(3);
         } else if (looker) {
+            const unsigned long long k0 = (verify & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
             if (it >= kb0 && it <= kb1) check_packets(it);
             lds_work(it, tb);
+            if (verify & 4) ((lu32_t)(uintptr_t)stat_lds)[9] += (uint32_t)(__builtin_amdgcn_s_memtime() - k0);   // the look-up wavefront's busy cycles
         } else if (GATHER && it >= kb0 && it <= kb1) {
             if constexpr (GATHER) {
                 uint32_t pairs = lds_pairs + (uint32_t)(it & 1) * kTgPairBytes, packets = c.lds_halo + ring(it) * (kTpBlock * 16);
@@ -688,6 +695,8 @@ __device__ __forceinline__ void tn_run_tile(const Lattice &d, const TileTask &tk
             st.phase[0] = sw[3] | ((unsigned long long)sw[4] << 32);
             st.phase[1] = sw[5] | ((unsigned long long)sw[6] << 32);
             st.phase[2] = sw[7] | ((unsigned long long)sw[10] << 32);   // (high half: HW_ID of the compute wavefront)
+            st.extra[0] = sw[8] | ((unsigned long long)sw[2] << 32);    // compute wavefront: cycles at the barrier | cycles inside the frame blocks
+            st.extra[1] = sw[9];                                         // look-up wavefront: busy cycles
             st.wait_ticks = sw[1] | ((unsigned long long)sw[2] << 32);
             st.start_tick = __builtin_amdgcn_s_memtime() - stats_out->total_ticks;
             st.total_ticks = wall_clock64() - stats_out->start_tick;

@@ -102,6 +102,7 @@ struct TileAux {
 struct TpStats {
     unsigned long long phase[3];   // shader cycles: (wait | check+sum << 32), (progress | requests << 32), (publish+checkpoint)
     unsigned long long wait_ticks, total_ticks, spins, start_tick;   // 100 MHz ticks (ka_engine_set_verify(4): ka_debug_tile_stats)
+    unsigned long long extra[2];   // 128-position tiles: (compute wavefront's cycles at the barrier | cycles in its frame blocks << 32), look-up wavefront's busy cycles
 };
 
 constexpr unsigned kTpLdsRequest = 40 * 1024;   // used: 32 KB rows + 2 KB packets + 2 KB publish staging
