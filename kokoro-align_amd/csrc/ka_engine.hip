@@ -271,8 +271,11 @@ int enqueue_tiles(ka_engine *e, const LaunchPlan &p, const BatchArgs &a, const D
         if (!contiguous) tl.pitch = 0;
     }
     if (p.narrow) {
-        const bool lookup = e->tile_gather != 0;
-        tl.lds = lookup ? (unsigned)e->tile_lds : lds;      // (the look-up form needs more than 40 KB anyway: the launch function takes the larger)
+        const int lookup = e->tile_gather < 0 ? 2 : e->tile_gather;       // 2: ka_tiled_stream.hpp (default); 1 / 0: ka_tiled_narrow.hpp's forms
+        // self-vouching packets: every slot of every boundary starts as the sentinel, in one fill (the -inf slots in front stay)
+        if (lookup == 2 && !(e->verify & 1) && p.halo_bytes)
+            KA_HIP(hipMemsetD32Async((hipDeviceptr_t)(e->ws + p.off_halo + p.ninf_bytes), (int)ka::kTpSentinel, p.halo_bytes / 4, stream));
+        tl.lds = lookup ? (unsigned)e->tile_lds : lds;      // (the look-up forms need more than 40 KB anyway: the launch function takes the larger)
         ka::launch_forward_tiled128(tl, lookup, stream);
     } else {
         tl.lds = lds;
@@ -665,7 +668,7 @@ int ka_debug_set_tile_width(ka_engine *e, int32_t positions)
 int ka_debug_set_tile_gather(ka_engine *e, int32_t how)
 {
     if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
-    if (how < -1 || how > 1) return fail(KA_ERR_BAD_ARGS, "ka_debug_set_tile_gather: -1, 0 or 1");
+    if (how < -1 || how > 2) return fail(KA_ERR_BAD_ARGS, "ka_debug_set_tile_gather: -1, 0, 1 or 2");
     e->tile_gather = how;
     return KA_OK;
 }

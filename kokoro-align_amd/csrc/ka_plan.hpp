@@ -259,7 +259,7 @@ struct LaunchPlan {
     // workspace offsets (bytes)
     size_t n_tasks = 0;
     size_t off_desc = 0, off_meta = 0, off_zero = 0, zero_bytes = 0, off_prog = 0, off_aux = 0, off_ticket = 0, off_tasks = 0, off_stats = 0;
-    size_t off_halo = 0, ninf_bytes = 0, total_bytes = 0;
+    size_t off_halo = 0, ninf_bytes = 0, halo_bytes = 0, total_bytes = 0;   // halo region: the -inf slots, then every tiled lattice's boundaries
     std::vector<Carve> cv;         // by the caller's index
 
     int32_t n_ring() const { return n_tiled + n_fast; }   // lattices whose checkpointed results backtrace_rc walks / the exact kernels may redo
@@ -402,6 +402,15 @@ inline void carve_workspace(LaunchPlan &p)
     p.ninf_bytes = p.n_tiled ? align_up((size_t)(ninf_slots + 2 * kTpBlock) * 16) : 0;
     off += p.ninf_bytes;
     p.cv.assign(n, Carve());
+    // ... then the halo slots of every tiled lattice, in one piece (one fill with the sentinel per launch: ka_tiled_stream.hpp)
+    p.halo_bytes = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        p.cv[i].halo = off;
+        if (sh[i].tiled) {
+            off += sh[i].halo_bytes;
+            p.halo_bytes += sh[i].halo_bytes;
+        }
+    }
     for (int32_t i = 0; i < n; ++i) {
         Carve &c = p.cv[i];
         c.labx = off;
@@ -410,8 +419,6 @@ inline void carve_workspace(LaunchPlan &p)
         off += bp_region_bytes(sh[i]);
         c.col = off;
         if (!sh[i].fast && !sh[i].tiled) off += align_up((size_t)sh[i].L * 2 * sizeof(float) + (size_t)sh[i].L * 2);
-        c.halo = off;
-        if (sh[i].tiled) off += sh[i].halo_bytes;
         c.map0 = c.map1 = c.entry = off;
         if (sh[i].par_bt) {
             const size_t R = (sh[i].tiled ? sh[i].ck_pitch : 4096) / 4;

@@ -1,16 +1,20 @@
 // ka_tiled128.hip — translation unit of the 128-position tile pipeline (ka_tiled_narrow.hpp): three wavefronts per tile
 // (compute, emission look-up, feeder) or two (compute with the look-up, feeder).
 #include "ka_launch.hpp"
-#include "ka_tiled_narrow.hpp"
+#include "ka_tiled_stream.hpp"
 
 #include <algorithm>
 
 namespace ka {
 
 template <int M, int PITCH, bool CONTIG>
-static void tiled128(const TileLaunch &a, bool lookup, hipStream_t s)
+static void tiled128(const TileLaunch &a, int lookup, hipStream_t s)
 {
-    if (lookup) {
+    if (lookup == 2) {      // round 4: packets that vouch for themselves (ka_tiled_stream.hpp; the halo region holds the sentinel)
+        const unsigned need = (unsigned)TsLds<PITCH, CONTIG>::kTotal;
+        hipLaunchKernelGGL((forward_ts_kernel<M, PITCH, CONTIG>), dim3((unsigned)a.n_tasks), dim3(192), std::max(need, a.lds), s, a.lats, a.tasks, a.n_tasks, a.meta,
+                           a.halo, a.aux, a.ticket, a.verify, a.stats);
+    } else if (lookup) {
         const unsigned need = (unsigned)TnLds<PITCH, CONTIG, true>::kTotal;
         hipLaunchKernelGGL((forward_tn_kernel<M, PITCH, CONTIG, true>), dim3((unsigned)a.n_tasks), dim3(192), std::max(need, a.lds), s, a.lats, a.tasks, a.n_tasks,
                            a.meta, a.halo, a.prog, a.aux, a.ticket, a.verify, a.stats);
@@ -19,7 +23,7 @@ static void tiled128(const TileLaunch &a, bool lookup, hipStream_t s)
                            a.prog, a.aux, a.ticket, a.verify, a.stats);
 }
 
-void launch_forward_tiled128(const TileLaunch &a, bool lookup, hipStream_t s)
+void launch_forward_tiled128(const TileLaunch &a, int lookup, hipStream_t s)
 {
     if (a.pitch == 256) return tiled128<4, 256, true>(a, lookup, s);
     if (a.pitch == 156) return tiled128<4, 156, true>(a, lookup, s);
