@@ -90,7 +90,7 @@ inline void plan_tiles(Shape &sh, int32_t V, int32_t beam, int32_t max_move, int
 
 // Tile width of a launch's tiled lattices: 128 positions (two cells per lane and three wavefronts per tile, ka_tiled_narrow.hpp:
 // a frame of half the instructions, twice the tiles and twice the hand-offs, 46-52 KB of LDS per tile) while the tiles alive
-// at once are no more than 2.6 per workgroup slot of the device, else 256.  Measured on prefixes of the corpus stand-in, all
+// at once are no more than 3.2 per workgroup slot of the device, else 256.  Measured on prefixes of the corpus stand-in, all
 // tiled, V = 39: three workgroups per CU (tools/sweep_width.py, profiles/r03_sweep_width.jsonl): against 256 positions the
 // forward kernel takes 0.66 x the time for one chapter, 0.70 x for 64 (~580 tiles alive), 0.78 x for 128, 0.94 x for 200 (~1800),
 // 1.17 x for 320 (~2900).  Tiles that never die (a band as wide as the label axis) must all hold a slot at once: the whole
@@ -108,7 +108,9 @@ inline bool narrow_tiles_pay(const std::vector<Shape> &plans, int32_t n_simd, in
     }
     if (forced == kTnTile) return true;
     const int64_t slots = (int64_t)(n_simd / 4) * 3;   // 46-52 KB of LDS per workgroup: three per CU
-    return permanent <= slots && 5 * alive_now <= 13 * (slots - permanent);
+    // (round 4, ka_tiled_stream.hpp against 256 positions, profiles/r04_sweep_width.jsonl: 0.49 x for one chapter, 0.56 x for 64,
+    //  0.73 x for 160, 0.93 x for 250 (~2250 tiles alive), 1.04 x for 320 (~2900): 3.2 tiles per slot; round 3's kernels: 2.6)
+    return permanent <= slots && 5 * alive_now <= 16 * (slots - permanent);
 }
 
 inline bool shape_of(int64_t T, int64_t S, int32_t V, int32_t beam, int32_t max_move, Shape &sh)

@@ -18,7 +18,7 @@ for K in Ks:
     b.engine.set_profiling(True)
     row = {"lattices": K, "frames": sum(t for t, _ in shapes), "longest": max(t for t, _ in shapes)}
     ref = None
-    for width, gather in ((256, -1), (128, 0), (128, 1)):
+    for width, gather in ((256, -1), (128, 1), (128, 2)):
         b.engine.set_tile_width(width)
         b.engine.set_tile_gather(gather)
         b.run()
@@ -26,7 +26,7 @@ for K in Ks:
         for _ in range(3):
             b.run()
             ms.append(b.engine.last_kernel_ms()["forward"])
-        row[f"forward_ms_{width}" + ("_feeder_lookup" if gather == 1 else "")] = round(min(ms), 4)
+        row[f"forward_ms_{width}" + {-1: "", 1: "_round3_three_waves", 2: "_streamed"}[gather]] = round(min(ms), 4)
         paths = [p.clone() for p in b.path]
         if ref is None:
             ref = paths
