@@ -237,6 +237,18 @@ hipError_t join_aux(ka_engine *e, hipStream_t stream, int k)
     return er != hipSuccess ? er : hipStreamWaitEvent(stream, e->sync[k], 0);
 }
 
+// 128-position tiles: which kernel form the engine's setting selects (2: ka_tiled_stream.hpp, the default; 1 / 0: round 3's)
+int narrow_form(const ka_engine *e) { return e->tile_gather < 0 ? 2 : e->tile_gather; }
+
+// The halo slots of the launch start as the NaN sentinel: always for ka_tiled_stream.hpp's self-vouching packets, and under
+// ka_engine_set_verify(1) for the other forms (a tile that consumes a slot nobody wrote reports KA_ERR_INTERNAL).
+int fill_halo_sentinel(ka_engine *e, const LaunchPlan &p, hipStream_t stream)
+{
+    if (!p.halo_bytes || !((e->verify & 1) || (p.narrow && narrow_form(e) == 2))) return KA_OK;
+    KA_HIP(hipMemsetD32Async((hipDeviceptr_t)(e->ws + p.off_halo + p.ninf_bytes), (int)ka::kTpSentinel, p.halo_bytes / 4, stream));
+    return KA_OK;
+}
+
 // ---- the tile pipeline of the launch's tiled lattices (descriptors [0, n_tiled)) ----
 int enqueue_tiles(ka_engine *e, const LaunchPlan &p, const BatchArgs &a, const DevicePtrs &dv, hipStream_t stream)
 {
@@ -245,11 +257,6 @@ int enqueue_tiles(ka_engine *e, const LaunchPlan &p, const BatchArgs &a, const D
     // run at 95-106 ns per frame instead of 55-62, and a chain runs at the pace of its slowest tile (cfg5's whole lattice,
     // 391 tiles alive for all 500 000 frames: profiles/r03_tile_stats_cfg5_full.txt)
     const unsigned lds = e->tile_lds ? (unsigned)e->tile_lds : ((int64_t)p.n_tasks <= (int64_t)e->n_simd / 2 ? 2u * ka::kTpLdsRequest : ka::kTpLdsRequest);
-    // ka_engine_set_verify(1) (tests): every halo slot starts as a NaN pattern and a tile that consumes one reports KA_ERR_INTERNAL
-    if (e->verify & 1)
-        for (int32_t i = 0; i < p.n; ++i)
-            if (p.sh[i].tiled && p.sh[i].halo_bytes)
-                KA_HIP(hipMemsetD32Async((hipDeviceptr_t)(e->ws + p.cv[i].halo), (int)ka::kTpSentinel, p.sh[i].halo_bytes / 4, stream));
     ka::TileLaunch tl;
     tl.lats = dv.lats;
     tl.tasks = reinterpret_cast<const ka::TileTask *>(e->ws + p.off_tasks);
@@ -271,10 +278,7 @@ int enqueue_tiles(ka_engine *e, const LaunchPlan &p, const BatchArgs &a, const D
         if (!contiguous) tl.pitch = 0;
     }
     if (p.narrow) {
-        const int lookup = e->tile_gather < 0 ? 2 : e->tile_gather;       // 2: ka_tiled_stream.hpp (default); 1 / 0: ka_tiled_narrow.hpp's forms
-        // self-vouching packets: every slot of every boundary starts as the sentinel, in one fill (the -inf slots in front stay)
-        if (lookup == 2 && !(e->verify & 1) && p.halo_bytes)
-            KA_HIP(hipMemsetD32Async((hipDeviceptr_t)(e->ws + p.off_halo + p.ninf_bytes), (int)ka::kTpSentinel, p.halo_bytes / 4, stream));
+        const int lookup = narrow_form(e);
         tl.lds = lookup ? (unsigned)e->tile_lds : lds;      // (the look-up forms need more than 40 KB anyway: the launch function takes the larger)
         ka::launch_forward_tiled128(tl, lookup, stream);
     } else {
@@ -421,7 +425,6 @@ int enqueue_impl(ka_engine *e, int32_t n, const BatchArgs &a, int32_t V, int32_t
     e->h_meta = reinterpret_cast<int32_t *>(e->pin + align_up((size_t)n * sizeof(ka::Lattice)));
     ka::TileTask *h_tasks = reinterpret_cast<ka::TileTask *>(e->pin + align_up((size_t)n * sizeof(ka::Lattice)) + align_up((size_t)n * 16));
     fill_descriptors(e, p, a, h_lats);
-    if (p.n_tiled) ka::plan::fill_tile_tasks(p, h_tasks);
     if (mem == KA_MEM_HOST)
         for (int32_t i = 0; i < n; ++i) {
             KA_HIP(hipMemcpy2DAsync(e->ws + p.cv[i].lp, (size_t)V * 4, a.log_probs[i], (size_t)a.ld[i] * 4, (size_t)V * 4, (size_t)p.sh[i].T,
@@ -433,16 +436,22 @@ int enqueue_impl(ka_engine *e, int32_t n, const BatchArgs &a, int32_t V, int32_t
     dv.meta = reinterpret_cast<int32_t *>(e->ws + p.off_meta);
     KA_HIP(hipMemcpyAsync(dv.lats, h_lats, (size_t)n * sizeof(ka::Lattice), hipMemcpyHostToDevice, stream));
     KA_HIP(hipMemsetAsync(dv.meta, 0, (size_t)n * 16, stream));
+    // the device starts on what needs no tile tasks - the fills of the tile pipeline's regions, the label preparation - while
+    // the host lists the tasks (a book has ~10 000)
     if (p.n_tiled) {
-        KA_HIP(hipMemcpyAsync(e->ws + p.off_tasks, h_tasks, p.n_tasks * sizeof(ka::TileTask), hipMemcpyHostToDevice, stream));
         KA_HIP(hipMemsetAsync(e->ws + p.off_zero, 0, p.zero_bytes, stream));
         KA_HIP(hipMemsetD32Async((hipDeviceptr_t)(e->ws + p.off_prog), (int)ka::kTpProgDone, 1, stream));
         KA_HIP(hipMemsetD32Async((hipDeviceptr_t)(e->ws + p.off_halo), (int)0xff800000u, p.ninf_bytes / 4, stream));   // -inf packets
+        const int rcf = fill_halo_sentinel(e, p, stream);
+        if (rcf != KA_OK) return rcf;
     }
-
     if (e->profiling) KA_HIP(hipEventRecord(e->ev[0], stream));
     ka::launch_prep_labels(dv.lats, n, dv.meta, stream);
     if (e->profiling) KA_HIP(hipEventRecord(e->ev[1], stream));
+    if (p.n_tiled) {
+        ka::plan::fill_tile_tasks(p, h_tasks);
+        KA_HIP(hipMemcpyAsync(e->ws + p.off_tasks, h_tasks, p.n_tasks * sizeof(ka::TileTask), hipMemcpyHostToDevice, stream));
+    }
     ka::WaveForm wave_form = ka::kWaveExact;
     rc = enqueue_forward(e, p, a, dv, stream, &wave_form);
     if (rc != KA_OK) return rc;
@@ -785,6 +794,11 @@ int ka_debug_plan_tiles_width(int64_t T, int64_t S, int32_t V, int32_t beam_size
         !ka::plan::shape_of(T, S, V, beam_size, max_move, sh))
         return fail(KA_ERR_BAD_ARGS, "ka_debug_plan_tiles_width: bad arguments");
     ka::plan::plan_tiles(sh, V, beam_size, max_move, positions);
+    {   // the O(1) count the planner decides by must agree with the listing (the CPU tests of the tile plan come through here)
+        const ka::plan::TileCount tc = ka::plan::count_tiles(sh, V, beam_size, max_move, positions);
+        if (tc.tileable != sh.tileable || (sh.tileable && tc.n_tiles != (int64_t)sh.t_in.size()))
+            return fail(KA_ERR_INTERNAL, "ka_debug_plan_tiles_width: count_tiles disagrees with plan_tiles");
+    }
     if (!sh.tileable) return 0;
     for (size_t b = 0; b < sh.t_in.size() && b < (size_t)max_tiles; ++b) {
         t_in[b] = sh.t_in[b];
@@ -803,14 +817,16 @@ int ka_debug_plan_tiles(int64_t T, int64_t S, int32_t V, int32_t beam_size, int3
 int ka_debug_tile_width_choice(const int64_t *T, const int64_t *S, int32_t n, int32_t V, int32_t beam_size, int32_t max_move, int32_t n_simd)
 {
     if (n < 0 || (n > 0 && (!T || !S)) || n_simd < 4) return fail(KA_ERR_BAD_ARGS, "ka_debug_tile_width_choice: bad arguments");
-    std::vector<Shape> plans(n);
+    std::vector<ka::plan::TileCount> counts(n);
+    std::vector<int64_t> widths(n);
     for (int32_t i = 0; i < n; ++i) {
-        if (!ka::plan::shape_of(T[i], S[i], V, beam_size, max_move, plans[i])) return fail(KA_ERR_BAD_ARGS, "ka_debug_tile_width_choice: bad shape");
-        ka::plan::plan_tiles(plans[i], V, beam_size, max_move, ka::kTpTile);
-        if (!plans[i].tileable) return 0;
-        ka::plan::plan_tiles(plans[i], V, beam_size, max_move, ka::kTnTile);
+        Shape sh;
+        if (!ka::plan::shape_of(T[i], S[i], V, beam_size, max_move, sh)) return fail(KA_ERR_BAD_ARGS, "ka_debug_tile_width_choice: bad shape");
+        if (!ka::plan::count_tiles(sh, V, beam_size, max_move, ka::kTpTile).tileable) return 0;
+        counts[i] = ka::plan::count_tiles(sh, V, beam_size, max_move, ka::kTnTile);
+        widths[i] = sh.W;
     }
-    return ka::plan::narrow_tiles_pay(plans, n_simd, 0) ? ka::kTnTile : ka::kTpTile;
+    return ka::plan::narrow_tiles_pay(counts, widths, n_simd, 0) ? ka::kTnTile : ka::kTpTile;
 }
 
 int ka_debug_auto_split(const int64_t *T, int32_t n, int32_t tiles_alive, int32_t n_simd, int32_t *n_tiled, int32_t *n_parallel)

@@ -58,13 +58,44 @@ inline void plan_tiles(Shape &sh, int32_t V, int32_t beam, int32_t max_move, int
     const int64_t n_tiles = ceil_div(L, P);
     sh.t_in.clear();
     sh.t_end.clear();
+    {   // (tiles a band of B positions keeps alive at once, plus those it passes through: no reallocation while they are listed)
+        const size_t guess = (size_t)std::min<int64_t>(n_tiles, 16 + (B + L) / P);
+        sh.t_in.reserve(guess);
+        sh.t_end.reserve(guess);
+    }
     sh.n_final = 0;
     sh.halo_bytes = 0;
+    // ceil((x - B + h + 1) T / L) and ceil((z + h) T / L) for x = b P, z = (b + 1) P, b = 0, 1, ...: both numerators grow by P T per
+    // tile, so the quotients are stepped (one division per lattice, not two per tile: a corpus launch lists 10^5 tiles)
+    const int64_t step_q = (P * T) / L, step_r = (P * T) % L;
+    int64_t qi = 0, ri = 0, qe, re;                       // floor((numerator + L - 1) / L) and its remainder
+    bool started = false;                                 // (the t_in formula applies from the first tile with x >= B)
+    {
+        const int64_t e0 = (P + h) * T + L - 1;
+        qe = e0 / L;
+        re = e0 % L;
+    }
     for (int64_t b = 0; b < n_tiles; ++b) {
-        const int64_t x = b * P, z = (b + 1) * P;
-        const int64_t ti = x < B ? 0 : ceil_div((x - B + h + 1) * T, L);
+        const int64_t x = b * P;
+        int64_t ti = 0;
+        if (x >= B) {
+            if (!started) {
+                const int64_t a0 = (x - B + h + 1) * T + L - 1;
+                qi = a0 / L;
+                ri = a0 % L;
+                started = true;
+            }
+            ti = qi;
+            qi += step_q;
+            ri += step_r;
+            if (ri >= L) { ri -= L; ++qi; }
+        }
+        const int64_t te_full = qe;
+        qe += step_q;
+        re += step_r;
+        if (re >= L) { re -= L; ++qe; }
         if (ti >= T) break;
-        const int64_t te = std::min<int64_t>(T, ceil_div((z + h) * T, L));
+        const int64_t te = std::min<int64_t>(T, te_full);
         if (te <= ti) return;   // the band jumps over a whole tile in one frame (L/T > P): not worth a pipeline
         sh.t_in.push_back((int32_t)ti);
         sh.t_end.push_back((int32_t)te);
@@ -88,6 +119,30 @@ inline void plan_tiles(Shape &sh, int32_t V, int32_t beam, int32_t max_move, int
     sh.tileable = true;
 }
 
+// How many tiles plan_tiles would list and whether the shape runs tiled at all, in O(1): the decisions of plan_forms (which
+// lattices run tiled, which width) need only the counts; listing every tile of every candidate at both widths was most of the
+// host's planning time (0.6 ms for a corpus launch).
+//   tile b exists iff t_in(b) < T;  for b P >= B:  ceil((b P - B + h + 1) T / L) < T  <=>  b P - B + h + 1 <= floor((T - 1) L / T)
+//   every tile lives at least one frame when the band plus a tile cannot be crossed in one: (P + B - 1) T >= L (else: list and see)
+struct TileCount {
+    bool tileable;
+    int64_t n_tiles;
+};
+inline TileCount count_tiles(const Shape &sh, int32_t V, int32_t beam, int32_t max_move, int64_t P)
+{
+    if (V > 64 || max_move > 4 || beam < 1 || sh.T >= (int64_t(1) << 26)) return {false, 0};
+    const int64_t T = sh.T, L = sh.L, B = beam, h = B / 2;
+    if ((P + B - 1) * T < L) {
+        Shape q = sh;
+        plan_tiles(q, V, beam, max_move, P);
+        return {q.tileable, (int64_t)q.t_in.size()};
+    }
+    const int64_t all = ceil_div(L, P);
+    const int64_t reach = ((T - 1) * L) / T + B - h - 1;       // largest b P whose tile still begins before frame T
+    const int64_t n = std::min<int64_t>(all, reach / P + 1);
+    return {n > 0, n};
+}
+
 // Tile width of a launch's tiled lattices: 128 positions (two cells per lane and three wavefronts per tile, ka_tiled_narrow.hpp:
 // a frame of half the instructions, twice the tiles and twice the hand-offs, 46-52 KB of LDS per tile) while the tiles alive
 // at once are no more than 3.2 per workgroup slot of the device, else 256.  Measured on prefixes of the corpus stand-in, all
@@ -95,14 +150,14 @@ inline void plan_tiles(Shape &sh, int32_t V, int32_t beam, int32_t max_move, int
 // forward kernel takes 0.66 x the time for one chapter, 0.70 x for 64 (~580 tiles alive), 0.78 x for 128, 0.94 x for 200 (~1800),
 // 1.17 x for 320 (~2900).  Tiles that never die (a band as wide as the label axis) must all hold a slot at once: the whole
 // 500 000 x 100 001 lattice, 782 tiles of 128 positions on 512 slots, took 89 ms instead of 56.
-// `plans`: the 128-position plan of every tiled lattice (tileable or not).  forced: 0 = by the rule, 128, 256.
-inline bool narrow_tiles_pay(const std::vector<Shape> &plans, int32_t n_simd, int32_t forced)
+// `counts`: the 128-position tile count of every tiled lattice; `W`: their band widths.  forced: 0 = by the rule, 128, 256.
+inline bool narrow_tiles_pay(const std::vector<TileCount> &counts, const std::vector<int64_t> &W, int32_t n_simd, int32_t forced)
 {
-    if (forced == kTpTile || plans.empty()) return false;
+    if (forced == kTpTile || counts.empty()) return false;
     int64_t alive_now = 0, permanent = 0;     // tiles alive at once: of banded lattices (they come and go), of those that are all band
-    for (const Shape &p : plans) {
-        if (!p.tileable) return false;        // (L/T above 128: the band jumps over a whole tile in one frame)
-        const int64_t n_tiles = (int64_t)p.t_in.size(), in_band = (p.W + 2 * kTnTile - 1) / kTnTile;
+    for (size_t j = 0; j < counts.size(); ++j) {
+        if (!counts[j].tileable) return false;        // (L/T above 128: the band jumps over a whole tile in one frame)
+        const int64_t n_tiles = counts[j].n_tiles, in_band = (W[j] + 2 * kTnTile - 1) / kTnTile;
         if (n_tiles <= in_band) permanent += n_tiles;
         else alive_now += in_band;
     }
@@ -288,10 +343,11 @@ inline int32_t plan_forms(LaunchPlan &p, int32_t n, const int64_t *T, const int6
     p.checkpointed_waves = kn.mode != kModeWaveExact;
     if (!kn.force_generic && (kn.mode == kModeTiled || kn.mode == kModeAuto)) {
         std::vector<int32_t> cand;      // fast-shaped lattices that could run tiled, longest first
+        std::vector<TileCount> wide(n, TileCount{false, 0});
         for (int32_t i = 0; i < n; ++i) {
             if (kn.mode == kModeAuto && sh[i].fast && sh[i].T >= (int64_t(1) << 26)) continue;   // (runs in the exact form)
-            plan_tiles(sh[i], V, beam_size, max_move);
-            if (!sh[i].tileable) continue;
+            wide[i] = count_tiles(sh[i], V, beam_size, max_move, kTpTile);
+            if (!wide[i].tileable) continue;
             if (kn.mode == kModeTiled || !sh[i].fast) sh[i].tiled = true;
             else cand.push_back(i);
         }
@@ -302,36 +358,27 @@ inline int32_t plan_forms(LaunchPlan &p, int32_t n, const int64_t *T, const int6
             for (size_t j = 0; j < cand.size(); ++j) {
                 const Shape &q = sh[cand[j]];
                 Ts[j] = q.T;
-                alive[j] = (int32_t)std::min<int64_t>((int64_t)q.t_in.size(), (q.W + 2 * kTpTile - 1) / kTpTile);
+                alive[j] = (int32_t)std::min<int64_t>(wide[cand[j]].n_tiles, (q.W + 2 * kTpTile - 1) / kTpTile);
             }
             const int32_t k = kn.split_tiled >= 0 ? std::min<int32_t>(kn.split_tiled, (int32_t)cand.size()) : auto_split_forward(Ts, alive, kn.n_simd);
             for (int32_t j = 0; j < k; ++j) sh[cand[j]].tiled = true;
         }
         for (int32_t i = 0; i < n; ++i) p.n_tiled += sh[i].tiled ? 1 : 0;
     }
-    // ---- tile width (narrow_tiles_pay above) ----
-    if (p.n_tiled > 0 && kn.tile_width != kTpTile) {
-        std::vector<Shape> alt;
-        for (int32_t i = 0; i < n; ++i) {
-            if (!sh[i].tiled) continue;
-            Shape q = sh[i];
-            plan_tiles(q, V, beam_size, max_move, kTnTile);
-            alt.push_back(std::move(q));
-        }
-        if (narrow_tiles_pay(alt, kn.n_simd, kn.tile_width)) {
-            p.narrow = true;
-            size_t j = 0;
+    // ---- tile width (narrow_tiles_pay above), then the tiles themselves, listed once, at that width ----
+    if (p.n_tiled > 0) {
+        if (kn.tile_width != kTpTile) {
+            std::vector<TileCount> counts;
+            std::vector<int64_t> widths;
             for (int32_t i = 0; i < n; ++i)
                 if (sh[i].tiled) {
-                    Shape &q = alt[j++];
-                    sh[i].t_in = std::move(q.t_in);
-                    sh[i].t_end = std::move(q.t_end);
-                    sh[i].n_final = q.n_final;
-                    sh[i].halo_bytes = q.halo_bytes;
-                    sh[i].ck_mask = q.ck_mask;
-                    sh[i].ck_pitch = q.ck_pitch;
+                    counts.push_back(count_tiles(sh[i], V, beam_size, max_move, kTnTile));
+                    widths.push_back(sh[i].W);
                 }
+            p.narrow = narrow_tiles_pay(counts, widths, kn.n_simd, kn.tile_width);
         }
+        for (int32_t i = 0; i < n; ++i)
+            if (sh[i].tiled) plan_tiles(sh[i], V, beam_size, max_move, p.narrow ? kTnTile : kTpTile);
     }
     // ---- chunk-parallel backtrace (ka_parallel_bt.hpp) for the longest of the checkpointed results: it recomputes the
     // whole band of every chunk, ~8x the serial form's work, but all chunks at once; the others are walked back serially,
@@ -446,55 +493,45 @@ inline void carve_workspace(LaunchPlan &p)
     p.total_bytes = off;
 }
 
-// Step 3a.  The tile tasks of the launch, sorted by first frame (then tile, then lattice): a tile's producer holds an
-// earlier ticket.  `tasks` has room for p.n_tasks entries.
+// Step 3a.  The tile tasks of the launch in ticket order: by first frame, so that a tile's producer (the tile below it in the same
+// lattice, whose first frame is not later) holds an earlier ticket and the tiles that are needed first get the first workgroup
+// slots.  Exactness of the order across lattices does not matter - a ticket that comes a little early only spins a little
+// longer - so the tasks are BUCKETED by first frame (256 frames a bucket, counting sort, stable: within a lattice tile b-1 stays
+// in front of tile b) instead of sorted: the host builds ~10 000 tasks per book while the GPU waits for them (round 3 sorted
+// them with a comparator: 0.5 ms for the Kokoro stand-in's 6000 tasks, 1.9 ms for the corpus).
+// `tasks` has room for p.n_tasks entries.
 inline void fill_tile_tasks(const LaunchPlan &p, TileTask *tasks)
 {
-    struct Key { int32_t t_in, tile, k; };
-    std::vector<Key> keys;
-    keys.reserve(p.n_tasks);
-    std::vector<size_t> first_word(p.n_tiled, 0);   // progress word of tile 0 of descriptor k (word 0 = "nothing below")
-    size_t w = 1;
-    for (int32_t k = 0; k < p.n_tiled; ++k) {
-        const Shape &q = p.sh[p.order[k]];
-        first_word[k] = w;
-        w += q.t_in.size();
-        for (size_t b = 0; b < q.t_in.size(); ++b) keys.push_back({q.t_in[b], (int32_t)b, k});
-    }
-    std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
-        if (a.t_in != b.t_in) return a.t_in < b.t_in;
-        if (a.tile != b.tile) return a.tile < b.tile;
-        return a.k < b.k;
-    });
-    std::vector<std::vector<size_t>> bound(p.n_tiled);   // halo region offset of the boundary above tile b
+    constexpr int kBucketShift = 8;
+    int32_t max_t_in = 0;
+    for (int32_t k = 0; k < p.n_tiled; ++k) max_t_in = std::max(max_t_in, p.sh[p.order[k]].t_in.back());
+    std::vector<uint32_t> start((size_t)(max_t_in >> kBucketShift) + 2, 0u);      // start[b + 1] = tasks in buckets <= b, then running cursors
+    for (int32_t k = 0; k < p.n_tiled; ++k)
+        for (int32_t ti : p.sh[p.order[k]].t_in) ++start[(size_t)(ti >> kBucketShift) + 1];
+    for (size_t b = 1; b < start.size(); ++b) start[b] += start[b - 1];
+    size_t word = 1;      // progress word of the lattice's tile 0 (word 0 = "nothing below"; the 256-position kernel's hand-off)
     for (int32_t k = 0; k < p.n_tiled; ++k) {
         const int32_t i = p.order[k];
         const Shape &q = p.sh[i];
-        size_t o = p.cv[i].halo - p.off_halo;
-        bound[k].resize(q.t_in.size());
-        for (size_t b = 0; b < q.t_in.size(); ++b) {
-            bound[k][b] = o;
-            o += align_up((size_t)(q.t_end[b + 1 < q.t_in.size() ? b + 1 : b] - q.t_in[b] + 1) * 16);
+        const size_t nt = q.t_in.size();
+        size_t below = 0, o = p.cv[i].halo - p.off_halo;      // halo region offset of the boundary below / above the current tile
+        for (size_t b = 0; b < nt; ++b) {
+            TileTask &tk = tasks[start[(size_t)(q.t_in[b] >> kBucketShift)]++];
+            tk.lat = k;
+            tk.tile = (int32_t)b;
+            tk.t_in = q.t_in[b];
+            tk.t_end = q.t_end[b];
+            // slot j of a boundary lies at its base + (j - t_in(lower tile)) * 16; the reader addresses from ITS t_in
+            tk.halo_in = b == 0 ? 0 : (int64_t)(below + (size_t)(q.t_in[b] - q.t_in[b - 1]) * 16);
+            tk.halo_out = (int64_t)o;
+            tk.fill_end = b + 1 < nt ? q.t_end[b + 1] - 1 : 0;
+            tk.prog_in = b == 0 ? 0 : (int32_t)(word + b - 1);
+            tk.prog_out = (int32_t)(word + b);
+            tk.below_end = b == 0 ? INT32_MAX : q.t_end[b - 1];
+            below = o;
+            o += align_up((size_t)(q.t_end[b + 1 < nt ? b + 1 : b] - q.t_in[b] + 1) * 16);
         }
-    }
-    for (size_t j = 0; j < keys.size(); ++j) {
-        const Key &key = keys[j];
-        const Shape &q = p.sh[p.order[key.k]];
-        const size_t b = (size_t)key.tile;
-        TileTask &tk = tasks[j];
-        tk = TileTask();
-        tk.lat = key.k;
-        tk.tile = key.tile;
-        tk.t_in = q.t_in[b];
-        tk.t_end = q.t_end[b];
-        // slot j of a boundary lies at its base + (j - t_in(lower tile)) * 16; the reader addresses from ITS t_in
-        tk.halo_in = b == 0 ? 0 : (int64_t)(bound[key.k][b - 1] + (size_t)(q.t_in[b] - q.t_in[b - 1]) * 16);
-        const bool has_above = b + 1 < q.t_in.size();
-        tk.halo_out = (int64_t)bound[key.k][b];
-        tk.fill_end = has_above ? q.t_end[b + 1] - 1 : 0;
-        tk.below_end = b == 0 ? INT32_MAX : q.t_end[b - 1];
-        tk.prog_in = b == 0 ? 0 : (int32_t)(first_word[key.k] + b - 1);
-        tk.prog_out = (int32_t)(first_word[key.k] + b);
+        word += nt;
     }
 }
 
