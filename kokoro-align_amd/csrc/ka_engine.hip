@@ -279,7 +279,15 @@ int enqueue_tiles(ka_engine *e, const LaunchPlan &p, const BatchArgs &a, const D
     }
     if (p.narrow) {
         const int lookup = narrow_form(e);
-        tl.lds = lookup ? (unsigned)e->tile_lds : lds;      // (the look-up forms need more than 40 KB anyway: the launch function takes the larger)
+        // Three of these workgroups fit a CU, and three that are alive together slow each other down: a tile puts ~28 cycles of
+        // traffic per frame on the CU's LDS pipe (pairs written and read, emission gathers, packets, staging) and runs a frame in
+        // 86, so the pipe saturates (the Kokoro stand-in's frames took 101 cycles at three per CU, 95 at two, 86 alone:
+        // tools/tile_stats_book.py).  While the launch's tiles that are alive at once fit two per CU - with some slack: a tile
+        // that waits a little for a slot costs less than sharing the pipe - ask for the LDS that keeps them at two.
+        const int64_t n_cu = e->n_simd / 4;
+        unsigned request = (unsigned)e->tile_lds;
+        if (!request && lookup && p.alive_tiles <= 11 * n_cu / 4) request = 64 * 1024;
+        tl.lds = lookup ? request : lds;      // (the look-up forms need more than 40 KB anyway: the launch function takes the larger)
         ka::launch_forward_tiled128(tl, lookup, stream);
     } else {
         tl.lds = lds;

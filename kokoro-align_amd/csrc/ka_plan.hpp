@@ -312,6 +312,7 @@ struct LaunchPlan {
     std::vector<int32_t> order;
     int32_t n_tiled = 0, n_fast = 0;
     bool narrow = false;           // the tiled lattices run in 128-position tiles
+    int64_t alive_tiles = 0;       // tiles of the launch that are alive at the same time (upper estimate: band width / tile width + 2 per lattice)
     bool checkpointed_waves = true;   // the one-wavefront lattices end in backtrace_rc (not in the exact form's stored back-pointers)
     // workspace offsets (bytes)
     size_t n_tasks = 0;
@@ -377,8 +378,12 @@ inline int32_t plan_forms(LaunchPlan &p, int32_t n, const int64_t *T, const int6
                 }
             p.narrow = narrow_tiles_pay(counts, widths, kn.n_simd, kn.tile_width);
         }
+        const int64_t P = p.narrow ? kTnTile : kTpTile;
         for (int32_t i = 0; i < n; ++i)
-            if (sh[i].tiled) plan_tiles(sh[i], V, beam_size, max_move, p.narrow ? kTnTile : kTpTile);
+            if (sh[i].tiled) {
+                plan_tiles(sh[i], V, beam_size, max_move, P);
+                p.alive_tiles += std::min<int64_t>((int64_t)sh[i].t_in.size(), (sh[i].W + 2 * P - 1) / P);
+            }
     }
     // ---- chunk-parallel backtrace (ka_parallel_bt.hpp) for the longest of the checkpointed results: it recomputes the
     // whole band of every chunk, ~8x the serial form's work, but all chunks at once; the others are walked back serially,

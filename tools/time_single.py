@@ -14,6 +14,7 @@ for name, T, S, V, beam in [("one tile T=50000 S=100", 50000, 100, 64, 1000), ("
     b.engine.set_mode(mode)
     b.engine.set_tile_width(int(os.environ.get("KA_TILE_WIDTH", "0")))
     b.engine.set_tile_gather(int(os.environ.get("KA_TILE_GATHER", "-1")))
+    b.engine.set_tile_lds(int(os.environ.get("KA_TILE_LDS", "0")))
     b.engine.set_profiling(True)
     b.run(raise_on_error=False)
     ms = []
@@ -21,4 +22,4 @@ for name, T, S, V, beam in [("one tile T=50000 S=100", 50000, 100, 64, 1000), ("
         b.run(raise_on_error=False)
         ms.append(b.engine.last_kernel_ms()["forward"])
     print(json.dumps({"case": name, "mode": mode, "lib": os.path.basename(os.environ.get("KA_LIBRARY", "default")), "forward_ms": min(ms), "ns_per_frame": min(ms) * 1e6 / T, "status": int(b.status[0])}), flush=True)
-    b.engine.set_tile_width(0); b.engine.set_mode("auto")
+    b.engine.set_tile_width(0); b.engine.set_mode("auto"); b.engine.set_tile_lds(0)
