@@ -78,9 +78,20 @@ def valu_bound(B, fwd_ms):
     clock_ghz = clock_ghz or 1.9
     waves_per_simd = max(1.0, B / N_SIMD)
     bound_ms = B * T * min_instr * 4.0 / (N_SIMD * clock_ghz * 1e9) * 1e3 if B >= N_SIMD else T * min_instr * 4.0 * waves_per_simd / (clock_ghz * 1e9) * 1e3
-    return {"min_vector_instructions_per_frame": min_instr, "measured_vector_instructions_per_frame": measured_instr or 46.3,
-            "cycles_per_wave_instruction": 4.0, "clock_ghz_under_load": clock_ghz, "clock_source": clock_source, "bound_ms": bound_ms,
-            "frac": bound_ms / fwd_ms}
+    out = {"min_vector_instructions_per_frame": min_instr, "measured_vector_instructions_per_frame": measured_instr or 46.3,
+           "cycles_per_wave_instruction": 4.0, "clock_ghz_under_load": clock_ghz, "clock_source": clock_source, "bound_ms": bound_ms,
+           "frac": bound_ms / fwd_ms}
+    # ... and the MEASURED floor (round 4): the same kernel built without its band handling and finiteness sum (results wrong by
+    # design), timed beside the real one on one box - the gap between model and kernel as a measurement
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_forward_floor.json")) as fh:
+            fl = json.load(fh)
+        if int(fl.get("lattices", -1)) == B:
+            out["measured_floor"] = {"floor_build_ms": fl["forward_kernel_alone_ms"]["floor"], "real_build_ms_same_box": fl["forward_kernel_alone_ms"]["real"],
+                                     "frac": fl["floor_over_real"], "source": "profiles/r04_forward_floor.json (make -C kokoro-align_amd/csrc floor; tools/ab_rc.sh real floor)"}
+    except Exception:
+        pass
+    return out
 
 
 def _numpy_one(_):

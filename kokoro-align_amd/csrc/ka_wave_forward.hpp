@@ -326,14 +326,18 @@ __device__ __forceinline__ void forward_ck(const Lattice &d, int32_t *meta)
                 const float rn = rows[(dd + 1) % D];
                 lrow[lane] = rn;                 // (LDS operations of a wave execute in order: the reads of row t are done)
                 e0[(dd + 1) & 1] = first_lane(rn);
+#ifndef KA_FWD_FLOOR
                 absum += __builtin_fabsf(rn);
+#endif
                 const float e0t = e0[dd & 1];
                 frame_scores<M, ZL, 3>(P, h1, h2, h3, E, vz, f32x2{e0t, e0t}, la, lrow);
                 // prefetch the row of frame t+D (the last row again once there is none: never consumed)
                 row_reload(rows[dd], lane_off, row_ahead);
                 row_ahead += t + D + 1 < T ? ld : 0;
                 if (dd == D - 1 && ((tb | mask_every4) & 4u) != 0) {
+#ifndef KA_FWD_FLOOR
                     mask_scores<15>(P, mk, NINF);
+#endif
                     if (((tb + D) & (kCkFrames - 1)) == 0 && tb + D < T) {
                         // checkpoint (tb+D)/kCkFrames: the scores after frame tb+D-1, [lane][16 cells], 4 KB.  Taken
                         // before the rare block resets re-labelled lanes: their old positions are still inputs
@@ -353,8 +357,15 @@ __device__ __forceinline__ void forward_ck(const Lattice &d, int32_t *meta)
                 h1 = wave_ror1(KA_P(P, 15));
                 h2 = wave_ror1(KA_P(P, 14));
                 h3 = wave_ror1(KA_P(P, 13));
+#ifdef KA_FWD_FLOOR
+                // KA_FWD_FLOOR (a timing build, results wrong by design: profiles/r04_forward_floor.json): the recurrence, the row
+                // pipeline and the checkpoint stores only - no band (no masks, no band steps, no re-labelling of lanes), no
+                // finiteness sum.  What the band handling costs is the difference to the real kernel.
+                if (false) {
+#else
                 rem += dr;
                 if (__builtin_expect(rem >= thr, 0)) {
+#endif
                     asm volatile("" ::: "memory");  // a real branch: the common frame pays an add, a compare and a jump
                     thr = thr_real;
                     if (dd != D - 1 || ((tb | mask_every4) & 4u) == 0) {
