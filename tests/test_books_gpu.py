@@ -398,3 +398,38 @@ def test_serial_backtrace_output_forms_on_a_book(books_on_device, gather):
     finally:
         eng.set_rc_gather(-1)
         _set(eng, "auto")
+
+
+def test_halo_sentinel_refill_survives_other_launches_in_between():
+    """ka_tiled_stream.hpp's packets vouch for themselves through a NaN sentinel that the engine refills BEHIND a launch's tiles
+    for the next launch (ka_engine.hip: refill_halo_sentinel).  Every launch lays its regions out from the start of the same
+    workspace, so a launch of another kind in between (one wavefront per lattice, the exact form, the generic kernels) writes
+    over the refilled slots: the next tiled launch must fill them itself.  A stale slot would pass for a packet."""
+    import torch
+    from kokoro_align_amd import workloads as W
+    from kokoro_align_amd.align import DeviceBatch
+    shapes = [(9000, 1500), (7000, 900), (4000, 700)]
+    want = O.lattice_batch_c(shapes, W.V_MODEL, 321, 1000, 4, threads=4)
+    lps, labs = W.device_book(shapes, seed0=321)
+    eng = _engine()
+    try:
+        tiled = DeviceBatch(lps, labs)
+        for between in ("wave", "wave_exact", "tiled/256", "generic", None):
+            _set(eng, "tiled/128+parallel")
+            tiled.run()
+            _check_against_oracle(tiled, want)
+            if between == "generic":        # V > 64: the generic kernels, whose byte-per-cell back-pointers cover the front of the workspace
+                glp = torch.zeros((3000, 80), dtype=torch.float32, device="cuda")
+                glab = torch.arange(1, 301, dtype=torch.int32, device="cuda") % 79 + 1
+                _set(eng, "auto")
+                DeviceBatch([glp], [glab]).run()
+            elif between is not None:
+                _set(eng, between)
+                other = DeviceBatch(lps, labs)
+                other.run()
+                _check_against_oracle(other, want)
+        _set(eng, "tiled/128+parallel")
+        tiled.run()
+        _check_against_oracle(tiled, want)
+    finally:
+        _set(eng, "auto")
