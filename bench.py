@@ -644,7 +644,7 @@ def main():
             out["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same batch size)" if traffic else None,
-                "kernel": {"auto": "forward_ck_kernel<4,false>", "wave": "forward_ck_kernel<4,false>", "tiled": "forward_tn_kernel<4> (128-position tiles) or forward_tp2_kernel<4> (256) by the number of tiles alive",
+                "kernel": {"auto": "forward_ck_kernel<4,false>", "wave": "forward_ck_kernel<4,false>", "tiled": "forward_ts_kernel<4> (128-position tiles) or forward_tp2_kernel<4> (256) by the number of tiles alive",
                            "wave_exact": "forward_w16_kernel<4,false>"}[args.mode],
                 "kernel_ms": fwd_s * 1e3, "launch_lattices": B,
                 "measured": ("serial pass after the timed region: one launch over all lattices, alone on the GPU (HIP events on its stream)" if G > 1

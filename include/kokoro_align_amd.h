@@ -166,14 +166,10 @@ int ka_debug_auto_split(const int64_t *T, int32_t n, int32_t tiles_alive, int32_
 /* LDS bytes a tile workgroup of the tiled form requests (0 = the library's choice; 40 KB lets four workgroups share a CU, 80 KB
  * two): an occupancy experiment knob, results are identical. */
 int ka_debug_set_tile_lds(ka_engine *e, int32_t bytes);
-/* Positions per tile of the tiled form: 256 (four cells per lane), 128 (two: ka_tiled_narrow.hpp, a shorter frame and twice
- * the tiles; only with two wavefronts per tile), or 0 = the library's choice (128 when all the launch's tiles are alive on
- * no more than half the device's SIMDs).  Results are identical. */
+/* Positions per tile of the tiled form: 256 (four cells per lane, two wavefronts per tile: ka_tiled2.hpp), 128 (two cells per lane,
+ * three wavefronts per tile, self-vouching halo packets: ka_tiled_stream.hpp - a shorter frame, twice the tiles), or 0 = the
+ * library's choice (128 while the tiles alive at once are no more than 3.2 per workgroup slot of the device).  Results are identical. */
 int ka_debug_set_tile_width(ka_engine *e, int32_t positions);
-/* 128-position tiles: 1 = the feeder wavefront looks up the emissions of a block and folds the band's kills into them (46-52 KB
- * of LDS per tile instead of 40: three tiles per CU), 0 = the compute wavefront reads the staged rows itself, -1 = the
- * library's choice.  Results are identical. */
-int ka_debug_set_tile_gather(ka_engine *e, int32_t how);
 /* Host-side probe of the library's choice (no GPU needed): the tile width - 128 or 256 - a launch of these n lattices, ALL run in
  * the tiled form, gets on a device of n_simd SIMDs; 0 if one of them is not run in the tiled form at all, a negative status for
  * bad arguments. */

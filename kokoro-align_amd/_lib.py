@@ -35,7 +35,7 @@ EXPORTS = [
     "ka_debug_tile_stats", "ka_engine_set_backtrace", "ka_debug_chunk_entries", "ka_debug_plan_tiles",
     "ka_engine_set_verify", "ka_stream_create", "ka_stream_destroy",
     "ka_debug_set_split", "ka_engine_workspace_bytes", "ka_debug_set_tile_lds",
-    "ka_debug_auto_split", "ka_debug_set_rc_gather", "ka_lstm_layer0_f32", "ka_debug_set_tile_width", "ka_debug_set_tile_gather", "ka_debug_tile_width_choice", "ka_debug_plan_tiles_width",
+    "ka_debug_auto_split", "ka_debug_set_rc_gather", "ka_lstm_layer0_f32", "ka_debug_set_tile_width", "ka_debug_tile_width_choice", "ka_debug_plan_tiles_width",
 ]
 
 
@@ -112,8 +112,6 @@ def load_library():
     L.ka_debug_set_tile_lds.argtypes = [vp, i32]
     L.ka_debug_tile_width_choice.restype = ctypes.c_int
     L.ka_debug_tile_width_choice.argtypes = [vp, vp, i32, i32, i32, i32, i32]
-    L.ka_debug_set_tile_gather.restype = ctypes.c_int
-    L.ka_debug_set_tile_gather.argtypes = [vp, i32]
     L.ka_debug_set_tile_width.restype = ctypes.c_int
     L.ka_debug_set_tile_width.argtypes = [vp, i32]
     L.ka_debug_set_split.restype = ctypes.c_int
@@ -233,10 +231,6 @@ class Engine:
     def set_tile_width(self, positions):
         """Positions per tile of the tiled form: 256, 128 (two-wavefront tiles only) or 0 = the library's choice."""
         check(self.lib.ka_debug_set_tile_width(self.handle, int(positions)), "ka_debug_set_tile_width")
-
-    def set_tile_gather(self, how):
-        """128-position tiles: the feeder looks up the emissions (1), the compute wavefront does (0), -1 = the library's choice."""
-        check(self.lib.ka_debug_set_tile_gather(self.handle, int(how)), "ka_debug_set_tile_gather")
 
     def set_verify(self, flags):
         """Self-checks of the tiled form's hand-off (ka_engine_set_verify): 1 = sentinel-filled halos, every consumed packet

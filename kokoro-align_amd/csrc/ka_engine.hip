@@ -87,7 +87,6 @@ struct ka_engine {
     int32_t last_V = 0, last_beam = 0, last_max_move = 0, last_mem = KA_MEM_DEVICE;
     int32_t verify = 0;                    // ka_engine_set_verify: self-checks of the tiled form's hand-off
     int32_t rc_gather = -1;                // ka_debug_set_rc_gather: -1 the library's rule, 0 / 1 the serial backtrace's output form
-    int32_t tile_gather = -1;              // ka_debug_set_tile_gather: a look-up wavefront per 128-position tile (1), none (0), -1 = the engine chooses
     int32_t tile_width = 0;                // ka_debug_set_tile_width: 0 = the engine chooses, 128 or 256
     int32_t tile_lds = 0;                  // ka_debug_set_tile_lds: LDS bytes a tile workgroup requests (0: the library's choice)
     int32_t split_tiled = -1, split_par = -1;   // ka_debug_set_split: how many of the longest lattices run tiled / are walked back chunk-parallel (-1: cost model)
@@ -244,12 +243,10 @@ hipError_t join_aux(ka_engine *e, hipStream_t stream, int k)
     return er != hipSuccess ? er : hipStreamWaitEvent(stream, e->sync[k], 0);
 }
 
-// 128-position tiles: which kernel form the engine's setting selects (2: ka_tiled_stream.hpp, the default; 1 / 0: round 3's)
-int narrow_form(const ka_engine *e) { return e->tile_gather < 0 ? 2 : e->tile_gather; }
-
-// The halo slots of the launch start as the NaN sentinel: always for ka_tiled_stream.hpp's self-vouching packets, and under
-// ka_engine_set_verify(1) for the other forms (a tile that consumes a slot nobody wrote reports KA_ERR_INTERNAL).
-bool wants_halo_sentinel(const ka_engine *e, const LaunchPlan &p) { return p.halo_bytes && ((e->verify & 1) || (p.narrow && narrow_form(e) == 2)); }
+// The halo slots of the launch start as the NaN sentinel: always for the 128-position tiles' self-vouching packets
+// (ka_tiled_stream.hpp), and under ka_engine_set_verify(1) for the 256-position form (a tile that consumes a slot nobody wrote
+// reports KA_ERR_INTERNAL).
+bool wants_halo_sentinel(const ka_engine *e, const LaunchPlan &p) { return p.halo_bytes && ((e->verify & 1) || p.narrow); }
 int fill_halo_sentinel(ka_engine *e, const LaunchPlan &p, hipStream_t stream)
 {
     if (!wants_halo_sentinel(e, p)) return KA_OK;
@@ -309,17 +306,15 @@ int enqueue_tiles(ka_engine *e, const LaunchPlan &p, const BatchArgs &a, const D
         if (!contiguous) tl.pitch = 0;
     }
     if (p.narrow) {
-        const int lookup = narrow_form(e);
         // Three of these workgroups fit a CU, and three that are alive together slow each other down: a tile puts ~28 cycles of
         // traffic per frame on the CU's LDS pipe (pairs written and read, emission gathers, packets, staging) and runs a frame in
         // 86, so the pipe saturates (the Kokoro stand-in's frames took 101 cycles at three per CU, 95 at two, 86 alone:
         // tools/tile_stats_book.py).  While the launch's tiles that are alive at once fit two per CU - with some slack: a tile
         // that waits a little for a slot costs less than sharing the pipe - ask for the LDS that keeps them at two.
         const int64_t n_cu = e->n_simd / 4;
-        unsigned request = (unsigned)e->tile_lds;
-        if (!request && lookup && p.alive_tiles <= 11 * n_cu / 4) request = 64 * 1024;
-        tl.lds = lookup ? request : lds;      // (the look-up forms need more than 40 KB anyway: the launch function takes the larger)
-        ka::launch_forward_tiled128(tl, lookup, stream);
+        tl.lds = (unsigned)e->tile_lds;      // (0: what the kernel needs, 46-52 KB; the launch function takes the larger)
+        if (!tl.lds && p.alive_tiles <= 11 * n_cu / 4) tl.lds = 64 * 1024;
+        ka::launch_forward_tiled128(tl, stream);
     } else {
         tl.lds = lds;
         ka::launch_forward_tiled256(tl, stream);
@@ -723,13 +718,6 @@ int ka_debug_set_tile_width(ka_engine *e, int32_t positions)
     return KA_OK;
 }
 
-int ka_debug_set_tile_gather(ka_engine *e, int32_t how)
-{
-    if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
-    if (how < -1 || how > 2) return fail(KA_ERR_BAD_ARGS, "ka_debug_set_tile_gather: -1, 0, 1 or 2");
-    e->tile_gather = how;
-    return KA_OK;
-}
 int ka_engine_set_profiling(ka_engine *e, int32_t on)
 {
     if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");

@@ -49,7 +49,7 @@ struct TileLaunch {
     int pitch;          // 0: rows staged one by one; 256 (V = 64) or 156 (V = 39): contiguous rows, copied as they lie
 };
 void launch_forward_tiled256(const TileLaunch &a, hipStream_t s);               // two wavefronts per 256-position tile (ka_tiled2.hpp)
-void launch_forward_tiled128(const TileLaunch &a, int lookup, hipStream_t s);   // 128-position tiles: 2 = ka_tiled_stream.hpp; ka_tiled_narrow.hpp with three (1) or two (0) wavefronts
+void launch_forward_tiled128(const TileLaunch &a, hipStream_t s);               // three wavefronts per 128-position tile (ka_tiled_stream.hpp); `prog` unused
 
 // ---- ka_misc.hip: log-softmax, hash generators, the log-prob producer's LSTM, the audio front end ----
 void launch_log_softmax(const float *in, float *out, int64_t T, int V, int64_t ld_in, int64_t ld_out, hipStream_t s);

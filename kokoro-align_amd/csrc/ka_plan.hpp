@@ -46,7 +46,7 @@ inline size_t par_bt_bytes(const Shape &sh)
            align_up((size_t)(chunks_of_T(sh.T) + supers_of_T(sh.T)) * 4);
 }
 
-// Which frames each tile of P positions (256, or 128: ka_tiled_narrow.hpp) is alive in, from the band of align.py:64-65:
+// Which frames each tile of P positions (256, or 128: ka_tiled_stream.hpp) is alive in, from the band of align.py:64-65:
 //   lo(t) = max(0, floor(L t / T) - B/2),  hi(t) = min(lo(t) + B, L)
 //   t_in(b)  = first t with hi(t) > P b        = 0 if P b < B, else ceil((P b - B + B/2 + 1) T / L)
 //   t_end(b) = first t with lo(t) >= P (b+1)   = ceil((P (b+1) + B/2) T / L), at most T
@@ -143,7 +143,7 @@ inline TileCount count_tiles(const Shape &sh, int32_t V, int32_t beam, int32_t m
     return {n > 0, n};
 }
 
-// Tile width of a launch's tiled lattices: 128 positions (two cells per lane and three wavefronts per tile, ka_tiled_narrow.hpp:
+// Tile width of a launch's tiled lattices: 128 positions (two cells per lane and three wavefronts per tile, ka_tiled_stream.hpp:
 // a frame of half the instructions, twice the tiles and twice the hand-offs, 46-52 KB of LDS per tile) while the tiles alive
 // at once are no more than 3.2 per workgroup slot of the device, else 256.  Measured on prefixes of the corpus stand-in, all
 // tiled, V = 39: three workgroups per CU (tools/sweep_width.py, profiles/r03_sweep_width.jsonl): against 256 positions the

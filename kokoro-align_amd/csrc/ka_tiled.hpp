@@ -354,7 +354,7 @@ __device__ __forceinline__ void tp_checkpoint(TpTile<M, ZL> &c, uint32_t t_next 
 // columns): a block is copied as it lies in memory, 1 KB per LDS-DMA instruction - 4 (V = 64) or 3 (V = 39) instructions per block instead of 16; an LDS-DMA
 // instruction costs the wave ~60 cycles to issue whatever it moves, and with 16 of them the per-block staging took
 // longer than the block's frames.
-// (tp2_run_tile in ka_tiled2.hpp, tn_run_tile in ka_tiled_narrow.hpp; the one-wavefront tile this header used to end with is gone:
+// (tp2_run_tile in ka_tiled2.hpp; the 128-position tiles have a header of their own, ka_tiled_stream.hpp; the one-wavefront tile this header used to end with is gone:
 // superseded by the two-wavefront tile in round 3 and removed in round 4.)
 
 }  // namespace ka

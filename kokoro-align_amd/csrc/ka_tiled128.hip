@@ -1,5 +1,5 @@
-// ka_tiled128.hip — translation unit of the 128-position tile pipeline (ka_tiled_narrow.hpp): three wavefronts per tile
-// (compute, emission look-up, feeder) or two (compute with the look-up, feeder).
+// ka_tiled128.hip — translation unit of the 128-position tile pipeline (ka_tiled_stream.hpp): a workgroup of three wavefronts
+// per tile - compute, emission look-up, feeder.
 #include "ka_launch.hpp"
 #include "ka_tiled_stream.hpp"
 
@@ -8,30 +8,22 @@
 namespace ka {
 
 template <int M, int PITCH, bool CONTIG>
-static void tiled128(const TileLaunch &a, int lookup, hipStream_t s)
+static void tiled128(const TileLaunch &a, hipStream_t s)
 {
-    if (lookup == 2) {      // round 4: packets that vouch for themselves (ka_tiled_stream.hpp; the halo region holds the sentinel)
-        const unsigned need = (unsigned)TsLds<PITCH, CONTIG>::kTotal;
-        hipLaunchKernelGGL((forward_ts_kernel<M, PITCH, CONTIG>), dim3((unsigned)a.n_tasks), dim3(192), std::max(need, a.lds), s, a.lats, a.tasks, a.n_tasks, a.meta,
-                           a.halo, a.aux, a.ticket, a.verify, a.stats);
-    } else if (lookup) {
-        const unsigned need = (unsigned)TnLds<PITCH, CONTIG, true>::kTotal;
-        hipLaunchKernelGGL((forward_tn_kernel<M, PITCH, CONTIG, true>), dim3((unsigned)a.n_tasks), dim3(192), std::max(need, a.lds), s, a.lats, a.tasks, a.n_tasks,
-                           a.meta, a.halo, a.prog, a.aux, a.ticket, a.verify, a.stats);
-    } else
-        hipLaunchKernelGGL((forward_tn_kernel<M, PITCH, CONTIG, false>), dim3((unsigned)a.n_tasks), dim3(128), a.lds, s, a.lats, a.tasks, a.n_tasks, a.meta, a.halo,
-                           a.prog, a.aux, a.ticket, a.verify, a.stats);
+    const unsigned need = (unsigned)TsLds<PITCH, CONTIG>::kTotal;
+    hipLaunchKernelGGL((forward_ts_kernel<M, PITCH, CONTIG>), dim3((unsigned)a.n_tasks), dim3(192), std::max(need, a.lds), s, a.lats, a.tasks, a.n_tasks, a.meta, a.halo,
+                       a.aux, a.ticket, a.verify, a.stats);
 }
 
-void launch_forward_tiled128(const TileLaunch &a, int lookup, hipStream_t s)
+void launch_forward_tiled128(const TileLaunch &a, hipStream_t s)
 {
-    if (a.pitch == 256) return tiled128<4, 256, true>(a, lookup, s);
-    if (a.pitch == 156) return tiled128<4, 156, true>(a, lookup, s);
+    if (a.pitch == 256) return tiled128<4, 256, true>(a, s);
+    if (a.pitch == 156) return tiled128<4, 156, true>(a, s);
     switch (a.max_move) {
-    case 1: tiled128<1, 256, false>(a, lookup, s); break;
-    case 2: tiled128<2, 256, false>(a, lookup, s); break;
-    case 3: tiled128<3, 256, false>(a, lookup, s); break;
-    default: tiled128<4, 256, false>(a, lookup, s); break;
+    case 1: tiled128<1, 256, false>(a, s); break;
+    case 2: tiled128<2, 256, false>(a, s); break;
+    case 3: tiled128<3, 256, false>(a, s); break;
+    default: tiled128<4, 256, false>(a, s); break;
     }
 }
 

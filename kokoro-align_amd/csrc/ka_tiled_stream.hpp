@@ -1,10 +1,11 @@
 // ka_tiled_stream.hpp — the 128-position tile pipeline, round 4: packets that vouch for themselves, no drain between blocks.
 //
-// Same decomposition as ka_tiled_narrow.hpp's three-wavefront form (a workgroup per 128-position tile: the COMPUTE wavefront
-// runs the frames - 11 instructions each -, the LOOK-UP wavefront turns the staged log-prob rows into per-lane emission pairs
-// with the band's kills folded in as -inf, the FEEDER moves memory), same arithmetic, same checkpoints.  What changed is how a
-// tile talks to its neighbours and how the three wavefronts meet; both were what a chain of tiles - a lone lattice, a book's
-// longest chapter - actually paid for (profiles/r04_tile_stats_cfg2_before.txt: of the front tile's 3300 cycles per 32-frame
+// A workgroup of three wavefronts per 128-position tile (two cells per lane): the COMPUTE wavefront runs the frames - 11
+// instructions each -, the LOOK-UP wavefront turns the staged log-prob rows into per-lane emission pairs with the band's kills
+// folded in as -inf (a sum with -inf IS the kill: the compute wavefront has no band code and no branch), the FEEDER moves memory.
+// Round 3 had this decomposition too (ka_tiled_narrow.hpp, removed); what changed in round 4 is how a tile talks to its
+// neighbours and how the three wavefronts meet; both were what a chain of tiles - a lone lattice, a book's longest chapter -
+// actually paid for (profiles/r04_tile_stats_cfg2_before.txt: of the front tile's 3300 cycles per 32-frame
 // block 2700 were frames and 600 the code between two blocks; every tile boundary cost 5.3 us of hand-off lag, 79 of them in
 // BASELINE configs[1]):
 //
@@ -31,9 +32,102 @@
 // so at barrier k the pairs and packets of block k+1 are complete, and every buffer that is rewritten during epoch k+1 was last
 // read before barrier k (the compute wavefront drains its reads there: the one wait per block, ~an LDS latency minus frame 27).
 #pragma once
-#include "ka_tiled_narrow.hpp"
+#include "ka_tiled2.hpp"
 
 namespace ka {
+
+// ---- a tile of 128 positions: two cells per lane ----
+template <int M, bool ZL>
+struct TnTile {
+    uint32_t T, L, B, dq, dr;
+    uint32_t q0, r0, dq32, dr32, ev;
+    uint32_t KL, KE;
+    float inv_T;
+    __device__ __forceinline__ uint32_t lo_of(uint32_t q) const
+    {
+        const int32_t d = (int32_t)q - (int32_t)(B >> 1);
+        return (uint32_t)(d > 0 ? d : 0);
+    }
+    __device__ __forceinline__ uint32_t hi_of(uint32_t lo) const { return (L - lo < B) ? L : lo + B; }
+    int32_t base, t_in, t_end;
+    const char *lp;
+    size_t ld;
+    uint32_t lane_off;
+    const char *halo_in;
+    char *halo_out;
+    gu32w_t prog_in, prog_out;
+    char *ck;
+    uint32_t ck_pitch;
+    uint32_t ck_off;        // per lane: ((base + 2 lane) & ck_mask) * 4
+    f32x2 S;                // {blank at base + 2 lane, label at base + 2 lane + 1}
+    int la0;                // 4 * label of the lane's label cell
+    float vz0;
+    float absum;
+    uint32_t lds_rows, lds_halo;
+    uint32_t lds_stage;
+    uint32_t lds_packets;
+};
+
+// tp_band_block for a tile of 128 positions
+template <int M, bool ZL>
+__device__ __forceinline__ void tn_band_block(TnTile<M, ZL> &c, uint32_t tb, int lane)
+{
+    const uint32_t l1 = lane > 0 ? (uint32_t)lane - 1u : 0u;
+    const uint32_t x = c.r0 + l1 * c.dr;
+    uint32_t qe = (uint32_t)((float)x * c.inv_T);
+    qe -= (qe * c.T > x) ? 1u : 0u;
+    qe += (x - qe * c.T >= c.T) ? 1u : 0u;
+    uint32_t qa = c.q0 + l1 * c.dq + qe;
+    const uint32_t q_before = tb == 0 ? c.q0 : (c.r0 >= c.dr ? c.q0 - c.dq : c.q0 - c.dq - 1u);
+    qa = lane == 0 ? q_before : qa;
+    const uint32_t qn = (uint32_t)__builtin_amdgcn_update_dpp((int)qa, (int)qa, 0x130, 0xF, 0xF, false);
+    const uint32_t tile_lo = (uint32_t)c.base, tile_hi = (uint32_t)c.base + kTnTile;
+    const uint32_t lo_a = c.lo_of(qa), lo_n = c.lo_of(qn);
+    const uint32_t hi_a = c.hi_of(lo_a), hi_n = c.hi_of(lo_n);
+    const uint32_t t = tb - 1u + (uint32_t)lane;
+    const uint32_t la = lo_a > tile_lo ? lo_a : tile_lo, lb = lo_n < tile_hi ? lo_n : tile_hi;
+    const bool leave = la < lb;
+    c.KL = leave ? (la - tile_lo) | ((lb - la) << 16) : 0u;
+    const uint32_t ea = hi_a > tile_lo ? hi_a : tile_lo, eb = hi_n < tile_hi ? hi_n : tile_hi;
+    const bool enter = ea < eb && t + 1u < c.T;
+    c.KE = enter ? (ea - tile_lo) | ((eb - ea) << 16) : 0u;
+    const uint64_t b_leave = __builtin_amdgcn_ballot_w64(leave), b_enter = __builtin_amdgcn_ballot_w64(enter);
+    c.ev = (uint32_t)b_leave | (uint32_t)(b_enter >> 1);
+}
+template <int M, bool ZL>
+__device__ __forceinline__ void tn_band_advance(TnTile<M, ZL> &c)
+{
+    c.q0 += c.dq32;
+    c.r0 += c.dr32;
+    if (c.r0 >= c.T) { c.r0 -= c.T; ++c.q0; }
+}
+
+// The compute wavefront's LDS traffic goes through asm statements the compiler cannot see into, with the waits written by hand:
+// hipcc waits with lgkmcnt(0) at every branch merge, i.e. a frame would wait for the reads it has just issued and take an LDS
+// round trip (~120 cycles) however few instructions it has.  Here the reads run FOUR frames ahead, every frame issues the same
+// three LDS instructions in the same order, and the frame that needs the data of frame t+1 waits with a counted lgkmcnt: the
+// instructions of the two frames in between stay in flight.  (asm volatile statements keep their order; tools/lint_inflight.py
+// checks that no register is copied between its read and its wait.)
+struct TgIn {
+    f32x2 e;      // {blank emission, label emission} of the lane's two cells, -inf where the cell dies after the frame
+    f32x4 hp;     // packet of the tile below
+};
+template <int G>
+__device__ __forceinline__ void tg_read(TgIn &in, uint32_t pairs, uint32_t packets)
+{
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(in.e) : "v"(pairs), "n"(G * 512));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(in.hp) : "v"(packets), "n"(G * 16));
+}
+template <int N>
+__device__ __forceinline__ void tg_wait(TgIn &in)
+{
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(in.e), "+v"(in.hp) : "n"(N));
+}
+__device__ __forceinline__ void tg_wait_all(TgIn (&in)[4])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(in[0].e), "+v"(in[0].hp), "+v"(in[1].e), "+v"(in[1].hp), "+v"(in[2].e), "+v"(in[2].hp), "+v"(in[3].e), "+v"(in[3].hp));
+}
+
 
 // LDS map of a workgroup (bytes from the dynamic block's start)
 template <int PITCH, bool CONTIG>

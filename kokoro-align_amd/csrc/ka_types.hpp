@@ -68,7 +68,7 @@ struct Lattice {
 // meta[4*idx + {0,1,2,3}] = status, end position, flags (bit0: a transcript label is 0), total score bits
 __device__ __forceinline__ int32_t *meta_of(int32_t *meta, int idx) { return meta + 4 * (size_t)idx; }
 
-// ---- tiled forms (ka_tiled.hpp, ka_tiled2.hpp, ka_tiled_narrow.hpp) ----
+// ---- tiled forms (ka_tiled.hpp, ka_tiled2.hpp, ka_tiled_stream.hpp) ----
 constexpr int kTpCells = 4;                    // cells per lane
 constexpr int kTpTile = 64 * kTpCells;         // positions per tile
 constexpr int kTpBlock = 32;                   // frames per staging block (= the checkpoint interval)
@@ -90,7 +90,7 @@ struct TileTask {
     int32_t fill_end;   // last slot of the upper boundary that the tile above reads (its t_end - 1)
     int32_t prog_in;    // progress word of the tile below (word 0 holds kTpProgDone: nothing below tile 0)
     int32_t prog_out;   // progress word of this tile
-    int32_t below_end;  // t_end of the tile below (tile 0: INT32_MAX): the slots behind it hold -inf by construction (ka_tiled_narrow.hpp uses it)
+    int32_t below_end;  // t_end of the tile below (tile 0: INT32_MAX): the slots behind it hold -inf by construction (ka_tiled_stream.hpp uses it)
 };
 // per lattice, zeroed before every launch: terminal state by 64-bit atomicMax, arrival counter of the last-frame tiles
 struct TileAux {
@@ -110,22 +110,7 @@ constexpr int kTp2BandBytes = 64 * 8 + 16;           // per block: KL, KE of 64 
 constexpr int kTp2StageBytes = 2 * kTpStageBytes;   // publish staging, double-buffered (the feeder reads block it-1's while block it's is written)
 constexpr int kTnCells = 2;
 constexpr int kTnTile = 64 * kTnCells;
-// LDS map of a 128-position tile workgroup (ka_tiled_narrow.hpp); the host needs kTotal for the launch
-constexpr int kTgPairBytes = kTpBlock * 64 * 8;
-template <int PITCH, bool CONTIG, bool GATHER>
-struct TnLds {
-    static constexpr int kRowDmas = !CONTIG ? kTpBlock : (kTpBlock * PITCH + 1023) / 1024;
-    static constexpr int kRing = GATHER ? 2 : kTpRing;                                        // row slots
-    static constexpr int kSlot = GATHER && CONTIG ? kRowDmas * 1024 : kTpSlotBytes;           // bytes per row slot
-    static constexpr int kPkRing = GATHER ? 2 : kTpRing;                                      // packet slots (GATHER: the block being read, the one landing)
-    static constexpr int kStageBytes = GATHER ? 1536 : kTpStageBytes;                         // a publish staging buffer (GATHER: the idle lanes' scratch 8 bytes apart)
-    static constexpr int kHalo = kRing * kSlot;                                               // packets of the tile below: kPkRing slots of 32
-    static constexpr int kPoll = kHalo + kPkRing * kTpBlock * 16;
-    static constexpr int kStage = kPoll + 16;
-    static constexpr int kStat = kStage + 2 * kStageBytes;                                     // 12 diagnostic words, the ticket at +48
-    static constexpr int kBand = kStat + 64;                                                  // !GATHER: two band buffers;  GATHER: two pair buffers
-    static constexpr int kTotal = kBand + (GATHER ? 2 * kTgPairBytes : 2 * kTp2BandBytes);
-};
+constexpr int kTgPairBytes = kTpBlock * 64 * 8;   // a block of emission pairs of a 128-position tile (ka_tiled_stream.hpp)
 
 // ---- chunk-parallel backtrace (ka_parallel_bt.hpp) ----
 constexpr int kCmCells = 8;                      // cells per lane

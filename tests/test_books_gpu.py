@@ -17,10 +17,9 @@ from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 
-# "tiled/256", "tiled/128": the tile pipeline with the tile width forced (ka_tiled2.hpp / ka_tiled_narrow.hpp; plain "tiled" lets the
-# library choose by the number of tiles alive at once); "tiled/128n": 128 positions, the two-wavefront form whose compute
-# wavefront reads the staged rows itself (ka_debug_set_tile_gather(0))
-MODES = ["wave", "wave_exact", "tiled/256", "tiled/128", "tiled/128n", "wave+parallel", "tiled/256+parallel", "tiled/128+parallel", "auto"]
+# "tiled/256", "tiled/128": the tile pipeline with the tile width forced (ka_tiled2.hpp / ka_tiled_stream.hpp; plain "tiled" lets the
+# library choose by the number of tiles alive at once)
+MODES = ["wave", "wave_exact", "tiled/256", "tiled/128", "wave+parallel", "tiled/256+parallel", "tiled/128+parallel", "auto"]
 _oracle_cache = {}
 
 
@@ -62,8 +61,7 @@ def _set(eng, mode):
     """'form' or 'form+parallel' (chunk-parallel backtrace forced); 'auto' leaves both choices to the library"""
     form, _, bt = mode.partition("+")
     form, _, width = form.partition("/")
-    eng.set_tile_gather(0 if width.endswith("n") else -1)
-    eng.set_tile_width(int(width.rstrip("n") or 0))
+    eng.set_tile_width(int(width or 0))
     eng.set_mode(form)
     eng.set_backtrace(bt or ("auto" if form == "auto" else "serial"))
 
@@ -160,7 +158,7 @@ def test_full_lattice_mode_vs_oracle_reduced_size(T, S, V):
             want = O.ctc_best_path_c(lp, lab, beam, 4, return_total=True)
         except ValueError:
             want = None
-        for mode in ("auto", "tiled/128+parallel", "tiled/256", "tiled/128", "tiled/128n"):
+        for mode in ("auto", "tiled/128+parallel", "tiled/256", "tiled/128"):
             _set(eng, mode)
             try:
                 b = DeviceBatch(lps, labs, beam)
@@ -309,7 +307,7 @@ def test_meian_book_with_the_hand_off_self_check_on(books_on_device):
     want = _oracle("meian")
     eng = _engine()
     try:
-        for mode, flags in (("tiled/256", 1), ("tiled/256", 3), ("tiled/128", 1), ("tiled/128", 3), ("tiled/128n", 1)):
+        for mode, flags in (("tiled/256", 1), ("tiled/256", 3), ("tiled/128", 1), ("tiled/128", 3)):
             _set(eng, mode)
             eng.set_verify(flags)
             b = DeviceBatch(lps, labs)

@@ -13,7 +13,7 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["wave", "wave_exact", "tiled/256", "tiled/128", "tiled/128n", "wave+parallel", "tiled/256+parallel", "tiled/128+parallel"])
+@pytest.fixture(scope="module", params=["wave", "wave_exact", "tiled/256", "tiled/128", "wave+parallel", "tiled/256+parallel", "tiled/128+parallel"])
 def ka(request):
     """Every test runs in every kernel form: one wavefront per lattice checkpointed / exact,
     four wavefronts per lattice, the tile pipeline with tiles of 256 and of 128 positions - and the checkpointed forms once
@@ -27,13 +27,11 @@ def ka(request):
     mode, _, width = mode.partition("/")
     eng = _lib.default_engine(torch.cuda.current_device())
     eng.set_mode(mode)
-    eng.set_tile_width(int(width.rstrip("n") or 0))
-    eng.set_tile_gather(0 if width.endswith("n") else -1)     # "128n": the two-wavefront form of the 128-position tiles
+    eng.set_tile_width(int(width or 0))
     eng.set_backtrace(bt or "serial")
     yield ka
     eng.set_mode("auto")
     eng.set_tile_width(0)
-    eng.set_tile_gather(-1)
     eng.set_backtrace("auto")
 
 

@@ -9,7 +9,7 @@ import ctypes
 import numpy as np
 import pytest
 
-WIDTHS = [256, 128]       # positions per tile: ka_tiled.hpp / ka_tiled2.hpp, ka_tiled_narrow.hpp
+WIDTHS = [256, 128]       # positions per tile: ka_tiled2.hpp, ka_tiled_stream.hpp
 
 
 def _plan(T, S, V, beam, max_move=4, cap=4096, width=256):

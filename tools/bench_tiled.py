@@ -22,7 +22,6 @@ def timed(lps, labs, mode, beam=1000, reps=3):
     b = DeviceBatch(lps, labs, beam)
     b.engine.set_mode(mode)
     b.engine.set_tile_width(int(os.environ.get("KA_TILE_WIDTH", "0")))
-    b.engine.set_tile_gather(int(os.environ.get("KA_TILE_GATHER", "-1")))
     b.engine.set_profiling(True)
     b.run()
     t0 = time.perf_counter()

@@ -15,7 +15,6 @@ for (T, S), seed in zip(shapes, seeds):
 b = DeviceBatch(lps, labs)
 e = b.engine
 e.set_tile_width(int(os.environ.get("KA_TILE_WIDTH", "0")))     # 0: the library chooses; 128 / 256 forced
-e.set_tile_gather(int(os.environ.get("KA_TILE_GATHER", "-1")))
 def run(mode, bt, split=(-1, -1)):
     e.set_mode(mode); e.set_backtrace(bt); e.set_split(*split)
     st = b.run(raise_on_error=False)

@@ -22,9 +22,9 @@ from oracle import oracle as O
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
-# (mode, backtrace, positions per tile: 0 = the library's choice, 128-position tiles: who looks up the emissions: -1 = the library's choice)
-FORMS = [("auto", "auto", 0, -1), ("tiled", "parallel", 256, -1), ("tiled", "serial", 256, -1), ("tiled", "parallel", 128, 0), ("tiled", "serial", 128, 1),
-         ("wave", "serial", 0, -1), ("wave", "parallel", 0, -1), ("wave_exact", "auto", 0, -1)]
+# (mode, backtrace, positions per tile: 0 = the library's choice)
+FORMS = [("auto", "auto", 0), ("tiled", "parallel", 256), ("tiled", "serial", 256), ("tiled", "parallel", 128), ("tiled", "serial", 128),
+         ("wave", "serial", 0), ("wave", "parallel", 0), ("wave_exact", "auto", 0)]
 eng = _lib.default_engine(0)
 t_end = time.time() + budget
 n_cases = n_lattices = 0
@@ -62,11 +62,10 @@ while time.time() < t_end and len(bad) < 10:
             wants.append(None)     # empty beam
     n_cases += 1
     n_lattices += len(shapes)
-    for mode, bt, width, gather in FORMS:
+    for mode, bt, width in FORMS:
         eng.set_mode(mode)
         eng.set_backtrace(bt)
         eng.set_tile_width(width)
-        eng.set_tile_gather(gather)
         res, status, total = ka.ctc_best_path_batch(lps, labs, beam, mm, return_status=True)
         for i, (r, st, w) in enumerate(zip(res, status, wants)):
             if w is None:
@@ -79,7 +78,6 @@ while time.time() < t_end and len(bad) < 10:
 eng.set_mode("auto")
 eng.set_backtrace("auto")
 eng.set_tile_width(0)
-eng.set_tile_gather(-1)
 print(f"fuzz seed {seed}: {n_cases} cases, {n_lattices} lattices x {len(FORMS)} forms, mismatches: {len(bad)}")
 for b in bad[:10]:
     print("  ", b)

@@ -33,7 +33,7 @@ import os
 import re
 import sys
 
-KERNELS = ("forward_ck", "forward_w16", "backtrace_rc", "backtrace_w16", "forward_tp", "forward_tn", "forward_ts", "chunk_map")
+KERNELS = ("forward_ck", "forward_w16", "backtrace_rc", "backtrace_w16", "forward_tp", "forward_ts", "chunk_map")
 VMEM = re.compile(r"\s*(global_load|global_store|buffer_load|buffer_store|flat_load|flat_store|global_atomic)\w*\s+(.*)")
 WAIT = re.compile(r"\s*s_waitcnt\s+(.*)")
 MOV = re.compile(r"\s*v_mov_b32(?:_e32|_dpp|_e64)?\s+(v[0-9]+),\s*(v[0-9]+)\b")

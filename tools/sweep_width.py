@@ -18,21 +18,20 @@ for K in Ks:
     b.engine.set_profiling(True)
     row = {"lattices": K, "frames": sum(t for t, _ in shapes), "longest": max(t for t, _ in shapes)}
     ref = None
-    for width, gather in ((256, -1), (128, 1), (128, 2)):
+    for width in (256, 128):
         b.engine.set_tile_width(width)
-        b.engine.set_tile_gather(gather)
         b.run()
         ms = []
         for _ in range(3):
             b.run()
             ms.append(b.engine.last_kernel_ms()["forward"])
-        row[f"forward_ms_{width}" + {-1: "", 1: "_round3_three_waves", 2: "_streamed"}[gather]] = round(min(ms), 4)
+        row[f"forward_ms_{width}"] = round(min(ms), 4)
         paths = [p.clone() for p in b.path]
         if ref is None:
             ref = paths
         else:
             row["same_paths"] = row.get("same_paths", True) and all(torch.equal(a, c) for a, c in zip(ref, paths))
     print(json.dumps(row), flush=True)
-    b.engine.set_tile_width(0); b.engine.set_tile_gather(-1); b.engine.set_mode("auto"); b.engine.set_profiling(False)
+    b.engine.set_tile_width(0); b.engine.set_mode("auto"); b.engine.set_profiling(False)
     del b, lps, labs
     torch.cuda.empty_cache()

@@ -13,7 +13,6 @@ lps, labs = W.device_book([(T, S)], V=V, seed0=0)
 b = DeviceBatch(lps, labs, beam)
 b.engine.set_mode("tiled")
 b.engine.set_tile_width(int(os.environ.get("KA_TILE_WIDTH", "0")))
-b.engine.set_tile_gather(int(os.environ.get("KA_TILE_GATHER", "-1")))
 b.engine.set_profiling(True)
 b.engine.set_verify(4)
 b.run(); b.run()

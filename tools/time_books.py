@@ -20,7 +20,6 @@ for name, shapes, seed0 in cases:
     b.engine.set_backtrace(bt)
     b.engine.set_tile_lds(lds)
     b.engine.set_tile_width(int(os.environ.get("KA_TILE_WIDTH", "0")))
-    b.engine.set_tile_gather(int(os.environ.get("KA_TILE_GATHER", "-1")))
     b.engine.set_profiling(True)
     b.run()
     rows = []

@@ -13,7 +13,6 @@ for name, T, S, V, beam in [("one tile T=50000 S=100", 50000, 100, 64, 1000), ("
     b = DeviceBatch(lps, labs, beam)
     b.engine.set_mode(mode)
     b.engine.set_tile_width(int(os.environ.get("KA_TILE_WIDTH", "0")))
-    b.engine.set_tile_gather(int(os.environ.get("KA_TILE_GATHER", "-1")))
     b.engine.set_tile_lds(int(os.environ.get("KA_TILE_LDS", "0")))
     b.engine.set_profiling(True)
     b.run(raise_on_error=False)
