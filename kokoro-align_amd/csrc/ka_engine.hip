@@ -251,10 +251,7 @@ int fill_halo_sentinel(ka_engine *e, const LaunchPlan &p, hipStream_t stream)
 {
     if (!wants_halo_sentinel(e, p)) return KA_OK;
     const size_t lo = p.off_halo + p.ninf_bytes, hi = lo + p.halo_bytes;
-    if (lo >= e->clean_lo && hi <= e->clean_hi && e->refill_done) {
-        KA_HIP(hipStreamWaitEvent(stream, e->refill_done, 0));      // the refill behind the last launch's tiles
-        return KA_OK;
-    }
+    if (lo >= e->clean_lo && hi <= e->clean_hi) return KA_OK;      // (the refill behind the last launch's tiles: enqueue_impl has waited for it)
     KA_HIP(hipMemsetD32Async((hipDeviceptr_t)(e->ws + lo), (int)ka::kTpSentinel, p.halo_bytes / 4, stream));
     return KA_OK;
 }
@@ -450,8 +447,13 @@ int enqueue_impl(ka_engine *e, int32_t n, const BatchArgs &a, int32_t V, int32_t
     if (rc != KA_OK) return rc;
     rc = ensure_pin(e, p.pinned_bytes());
     if (rc != KA_OK) return rc;
-    // (any launch lays its regions out from the start of the workspace: one without the sentinel protocol - other kernel forms,
-    //  the generic redo of ka_batch_finish - writes over what the last refill left clean)
+    // The refill behind the LAST launch's tiles runs on a stream of its own and nothing has waited for it yet: this launch
+    // lays its regions out from the start of the same workspace, and its first copies and fills must not race a fill that is
+    // still writing sentinels there (descriptors overwritten by a late refill were a memory fault with four engines running
+    // launches of different shapes: tools/stress_streams_tiled.py).
+    if (e->refill_done) KA_HIP(hipStreamWaitEvent(stream, e->refill_done, 0));
+    // (... and a launch without the sentinel protocol - other kernel forms, the generic redo of ka_batch_finish - writes over
+    //  what that refill left clean)
     if (!wants_halo_sentinel(e, p)) e->clean_lo = e->clean_hi = 0;
     e->dbg_tasks = p.off_tasks;
     e->dbg_stats = p.off_stats;

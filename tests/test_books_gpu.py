@@ -431,3 +431,32 @@ def test_halo_sentinel_refill_survives_other_launches_in_between():
         _check_against_oracle(tiled, want)
     finally:
         _set(eng, "auto")
+
+
+def test_a_launch_right_behind_a_big_tiled_one_is_not_hit_by_its_sentinel_refill():
+    """The refill of a book's halo region (hundreds of MB, ~0.2 ms, on the engine's own side stream) is still running when the
+    launch returns; the next launch - other shapes, so its labels and checkpoints lie where the book's halo slots were - must
+    wait for it.  Without the wait its workspace was overwritten under it (a memory fault with four engines, wrong paths here)."""
+    import torch
+    from kokoro_align_amd import workloads as W
+    from kokoro_align_amd.align import DeviceBatch
+    big = [(60000 - 700 * i, int(0.14 * (60000 - 700 * i))) for i in range(36)]
+    small = [(9000 - 500 * i, 1200 - 60 * i) for i in range(8)]
+    want = O.lattice_batch_c(small, W.V_MODEL, 777, 1000, 4, threads=8)
+    blp, blab = W.device_book(big, seed0=555)
+    slp, slab = W.device_book(small, seed0=777)
+    eng = _engine()
+    try:
+        _set(eng, "tiled/128+parallel")
+        book = DeviceBatch(blp, blab)
+        book.run()
+        assert all(int(p[-1]) == 2 * s for p, (_, s) in zip(book.path, big))
+        for mode in ("wave", "tiled/128+parallel", "wave_exact", "auto"):
+            _set(eng, "tiled/128+parallel")
+            book.run()
+            _set(eng, mode)
+            other = DeviceBatch(slp, slab)
+            other.run()
+            _check_against_oracle(other, want)
+    finally:
+        _set(eng, "auto")

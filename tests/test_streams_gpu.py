@@ -61,3 +61,37 @@ def test_a_failing_launch_raises_in_the_caller_and_leaves_the_others_done():
             assert np.array_equal(batches[0].path[k].cpu().numpy(), want[k][0])
     finally:
         sa.close()
+
+
+def test_corpus_dataset_by_dataset_on_four_engines():
+    """The reference's own loop (run_example.py:283-304: one dataset after the other) overlapped on four engines: several tile
+    pipelines share the device and every engine reuses ONE workspace for launches of different shapes.  Round 4 regression: the
+    sentinel refill behind a launch's tiles was still writing when the next, differently shaped launch laid its descriptors out
+    in the same memory (a GPU memory fault; tools/stress_streams_tiled.py)."""
+    import torch
+    from kokoro_align_amd import workloads as W
+    from kokoro_align_amd.align import DeviceBatch
+    from kokoro_align_amd.streams import StreamedAligner
+    per_ds = []
+    for k, (_, shapes) in enumerate(W.corpus()):
+        lps, labs = W.device_book(shapes, seed0=W.corpus_seed0(k))
+        per_ds.append((lps, labs, shapes))
+    ref = []
+    for lps, labs, _ in per_ds:       # reference: one wavefront per lattice, serial backtrace, one dataset at a time
+        b = DeviceBatch(lps, labs)
+        b.engine.set_mode("wave"); b.engine.set_backtrace("serial")
+        try:
+            b.run()
+        finally:
+            b.engine.set_mode("auto"); b.engine.set_backtrace("auto")
+        ref.append([p.clone() for p in b.path])
+    sa = StreamedAligner(4)
+    try:
+        batches = sa.bind([DeviceBatch(lps, labs) for lps, labs, _ in per_ds])
+        for rep in range(3):
+            status = sa.run(batches, repeat=2)
+            for k, (b, st) in enumerate(zip(batches, status)):
+                assert not (st != 0).any(), (rep, k)
+                assert all(torch.equal(a, c) for a, c in zip(ref[k], b.path)), (rep, k)
+    finally:
+        sa.close()
