@@ -364,10 +364,12 @@ int enqueue_backtrace(ka_engine *e, const LaunchPlan &p, const DevicePtrs &dv, h
             if (!q.par_bt) continue;
             ++n_par;
             total_chunks += chunks_of_T(q.T);
-            max_seg = std::max<int64_t>(max_seg, (q.W + 7 + ka::kCmOut - 1) / ka::kCmOut);
             max_sup = std::max<int64_t>(max_sup, supers_of_T(q.T));
             max_w = std::max<int64_t>(max_w, q.W);
         }
+        // segments of the band a map wavefront delivers: 408 positions (8 cells per lane) when every band fits one such
+        // wavefront, else 1048 (18 cells: the reference's band of 1000 in one wavefront instead of three)
+        max_seg = (max_w + 7 + ka::cm_out_for(max_w) - 1) / ka::cm_out_for(max_w);
         const bool two_backtraces = n_par > 0 && n_par < rc_hi;
         if (n_par < rc_hi) {      // one wavefront per lattice, chunk after chunk (skips the chunk-parallel ones)
             if (two_backtraces) KA_HIP(fork_aux(e, stream, 2));

@@ -211,7 +211,7 @@ inline size_t lattice_ws_bytes(const Shape &sh)
 //                                        a tile holds one of the chip's 1024 workgroup slots for 0.12 per frame it lives
 //                                        (corpus: 462 chapters, all tiled, 12.0 ms), vector-ALU time 0.023 per tile and frame
 //   serial backtrace                     chain 0.173 (8.7 ms / 50000), throughput 0.0675 per frame and SIMD (27 ms for 8192)
-//   chunk-parallel backtrace             0.00066 per frame of every lattice in it (it recomputes the whole band) + 0.12 ms
+//   chunk-parallel backtrace             0.00055 per frame of every lattice in it (it recomputes the whole band) + 0.12 ms
 // The two forward kernels run side by side on two streams, and so do the two backtraces; with lattices sorted longest first
 // the longest k go tiled and the longest m are walked back chunk-parallel, k and m minimising
 //   forward(k)   = chain (+) throughput, chain = max(chain_tiled(T_0) x tmult, chain_wave(T_k) x wmult),
@@ -231,7 +231,7 @@ struct AutoCosts {
     double tile_chain = 0.095, tile_slot = 0.12, tile_alu = 0.023;
     double tile_stretch = 0.55, wave_stretch = 0.40;
     double serial_chain = 0.173, serial_thr = 0.0675;
-    double par_frame = 0.00066, par_fixed = 120.0;
+    double par_frame = 0.00055, par_fixed = 120.0;      // (0.00066 until round 4's 18-cell map wavefronts: three map wavefronts per chunk became one)
     double fork = 15.0;      // a second stream and its two event waits
 };
 constexpr AutoCosts kAuto;
@@ -406,7 +406,7 @@ inline int32_t plan_forms(LaunchPlan &p, int32_t n, const int64_t *T, const int6
         for (int32_t j = 0; j < m && fits; ++j) {
             const Shape &q = sh[ring[j]];
             chunks += chunks_of_T(q.T);
-            fits = (q.W + 7 + kCmOut - 1) / kCmOut <= 65535 && supers_of_T(q.T) <= 65535 && chunks < (int64_t(1) << 31);
+            fits = (q.W + 7 + kCmOutWide - 1) / kCmOutWide <= 65535 && supers_of_T(q.T) <= 65535 && chunks < (int64_t(1) << 31);
         }
         if (!fits) m = 0;
         for (int32_t j = 0; j < m; ++j) sh[ring[j]].par_bt = true;

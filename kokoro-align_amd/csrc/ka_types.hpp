@@ -117,6 +117,10 @@ constexpr int kCmCells = 8;                      // cells per lane
 constexpr int kCmSpan = 64 * kCmCells;           // positions a wavefront recomputes
 constexpr int kCmWarm = 96;                      // lowest positions of the window: warm-up only (3 positions x 32 frames)
 constexpr int kCmOut = 408;                      // positions a wavefront delivers (a multiple of 8, <= kCmSpan - kCmWarm - 7)
+constexpr int kCmCellsWide = 18;                 // ... and the wide form (round 4): 1152 positions recomputed,
+constexpr int kCmOutWide = 64 * kCmCellsWide - kCmWarm - 8;   // 1048 delivered: the reference's band of 1000 in ONE wavefront
+// which form a launch's map kernel takes, from the widest band among its chunk-parallel lattices: positions a wavefront delivers
+inline int cm_out_for(int64_t max_w) { return max_w + 7 <= kCmOut ? kCmOut : kCmOutWide; }
 constexpr int kSuperChunks = 32;                 // chunks per super-chunk
 static_assert(kCmWarm == 3 * kCkFrames && kCmOut % 8 == 0 && kCmOut + kCmWarm <= kCmSpan, "window geometry");
 
