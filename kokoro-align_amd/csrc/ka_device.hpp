@@ -488,4 +488,14 @@ __device__ __forceinline__ float wave_shr1(float first, float x)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, first), __builtin_bit_cast(int, x), 0x138, 0xF, 0xF, false));
 }
 
+// Which compute unit this wavefront runs on, as an index into a kCuSlots-entry table: XCC_ID (3 bits) | HW_ID's se_id, sh_id,
+// cu_id (bits 15:8).  Used for SPEED only (ka_tiled_stream.hpp spreads the tiles that are alive first over the CUs).
+__device__ __forceinline__ uint32_t cu_slot()
+{
+    uint32_t hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    return ((xcc & 7u) << 8) | ((hw >> 8) & 0xffu);
+}
+
 }  // namespace ka

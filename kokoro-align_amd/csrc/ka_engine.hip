@@ -293,6 +293,7 @@ int enqueue_tiles(ka_engine *e, const LaunchPlan &p, const BatchArgs &a, const D
     tl.ticket = reinterpret_cast<uint32_t *>(e->ws + p.off_ticket);
     tl.verify = e->verify;
     tl.stats = reinterpret_cast<ka::TpStats *>(e->ws + p.off_stats);
+    tl.cu_rank = reinterpret_cast<uint32_t *>(e->ws + p.off_cu_rank);
     tl.max_move = p.max_move;
     // staging mode: when every tiled lattice's rows are contiguous (row stride = V, V = 64 or 39, 16-byte aligned) a block
     // is copied as it lies in memory (1 KB per LDS-DMA instruction); otherwise row by row

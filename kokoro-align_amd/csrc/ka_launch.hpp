@@ -44,6 +44,7 @@ struct TileLaunch {
     uint32_t *ticket;
     int verify;
     TpStats *stats;
+    uint32_t *cu_rank;  // [kCuSlots] workgroups per CU, zeroed per launch (128-position tiles: ka_tiled_stream.hpp)
     unsigned lds;       // LDS bytes a workgroup requests (at least what the kernel uses)
     int max_move;
     int pitch;          // 0: rows staged one by one; 256 (V = 64) or 156 (V = 39): contiguous rows, copied as they lie

@@ -316,7 +316,7 @@ struct LaunchPlan {
     bool checkpointed_waves = true;   // the one-wavefront lattices end in backtrace_rc (not in the exact form's stored back-pointers)
     // workspace offsets (bytes)
     size_t n_tasks = 0;
-    size_t off_desc = 0, off_meta = 0, off_zero = 0, zero_bytes = 0, off_prog = 0, off_aux = 0, off_ticket = 0, off_tasks = 0, off_stats = 0;
+    size_t off_desc = 0, off_meta = 0, off_zero = 0, zero_bytes = 0, off_prog = 0, off_aux = 0, off_ticket = 0, off_cu_rank = 0, off_tasks = 0, off_stats = 0;
     size_t off_halo = 0, ninf_bytes = 0, halo_bytes = 0, total_bytes = 0;   // halo region: the -inf slots, then every tiled lattice's boundaries
     std::vector<Carve> cv;         // by the caller's index
 
@@ -443,10 +443,12 @@ inline void carve_workspace(LaunchPlan &p)
             ninf_slots = std::max<int64_t>(ninf_slots, sh[i].t_end[0]);
         }
     p.off_zero = off;
-    p.zero_bytes = p.n_tiled ? align_up((1 + p.n_tasks) * 4 + (size_t)n * sizeof(TileAux) + 16, 16) : 0;
+    // ... [progress words | terminal records | ticket (16 bytes) | workgroups per CU (kCuSlots words: ka_tiled_stream.hpp)]
+    p.zero_bytes = p.n_tiled ? align_up((1 + p.n_tasks) * 4 + (size_t)n * sizeof(TileAux) + 16, 16) + (size_t)kCuSlots * 4 : 0;
     p.off_prog = p.off_zero;
     p.off_aux = p.off_zero + align_up((1 + p.n_tasks) * 4, 16);
     p.off_ticket = p.off_aux + (size_t)n * sizeof(TileAux);
+    p.off_cu_rank = p.off_ticket + 16;
     off += align_up(p.zero_bytes);
     p.off_tasks = off;
     off += align_up(p.n_tasks * sizeof(TileTask));
@@ -568,7 +570,7 @@ inline size_t workspace_upper_bound(int32_t n, const int64_t *T, const int64_t *
         total += plain;
     }
     if (tasks)
-        total += align_up(align_up((1 + tasks) * 4 + (size_t)n * sizeof(TileAux) + 16, 16)) + align_up(tasks * sizeof(TileTask)) +
+        total += align_up(align_up((1 + tasks) * 4 + (size_t)n * sizeof(TileAux) + 16, 16) + (size_t)kCuSlots * 4) + align_up(tasks * sizeof(TileTask)) +
                  align_up(tasks * sizeof(TpStats)) + align_up((size_t)(ninf_slots + 2 * kTpBlock) * 16);
     return total;
 }

@@ -12,7 +12,7 @@ static void tiled128(const TileLaunch &a, hipStream_t s)
 {
     const unsigned need = (unsigned)TsLds<PITCH, CONTIG>::kTotal;
     hipLaunchKernelGGL((forward_ts_kernel<M, PITCH, CONTIG>), dim3((unsigned)a.n_tasks), dim3(192), std::max(need, a.lds), s, a.lats, a.tasks, a.n_tasks, a.meta, a.halo,
-                       a.aux, a.ticket, a.verify, a.stats);
+                       a.aux, a.ticket, a.verify, a.stats, a.cu_rank);
 }
 
 void launch_forward_tiled128(const TileLaunch &a, hipStream_t s)

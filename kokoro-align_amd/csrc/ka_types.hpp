@@ -112,6 +112,8 @@ constexpr int kTnCells = 2;
 constexpr int kTnTile = 64 * kTnCells;
 constexpr int kTgPairBytes = kTpBlock * 64 * 8;   // a block of emission pairs of a 128-position tile (ka_tiled_stream.hpp)
 
+constexpr int kCuSlots = 2048;      // entries of a per-CU table indexed by cu_slot() (ka_device.hpp): XCC_ID (3 bits) | HW_ID's se, sh, cu (8 bits)
+
 // ---- chunk-parallel backtrace (ka_parallel_bt.hpp) ----
 constexpr int kCmCells = 8;                      // cells per lane
 constexpr int kCmSpan = 64 * kCmCells;           // positions a wavefront recomputes
