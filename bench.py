@@ -60,10 +60,11 @@ def algorithmic_bytes_per_frame():
 
 def valu_bound(B, fwd_ms):
     """The forward kernel is bound by vector-instruction issue, not by HBM: what the recurrence itself
-    needs per frame and wavefront - 24 max (7 candidates per blank/label pair of four cells, v_max3 takes three), 8 packed
+    needs per frame and wavefront - 20 max (7 candidates per blank/label pair, v_max3 takes three, and the two label cells of a
+    group of four share max(l0, b0): ka_device.hpp label_pair_max; 24 up to round 4's first bench line), 8 packed
     adds of the emissions, 3 DPP moves for the cells of the lane below - at the measured issue cost of 4 cycles per
     wave-instruction with 8 wavefronts per SIMD (profiles/r01_ubench_issue_rates.txt), against the kernel's time."""
-    min_instr = 24 + 8 + 3
+    min_instr = 20 + 8 + 3
     measured_instr = None
     clock_ghz = None
     f = os.path.join(ROOT, "profiles", "pmc_traffic.json")

@@ -399,6 +399,20 @@ __device__ __forceinline__ float cell_label_max(float a0, float a1, float a2, fl
     if constexpr (M == 3) return __builtin_fmaxf(__builtin_fmaxf(a0, a1), a2);
     return __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), a2), a3);
 }
+// The two label cells of a group of four (positions 4G+1 and 4G+3) with all four moves: the upper one's candidates are l1, b1,
+// l0, b0, the lower one's l0, b0, p1, p2 - max(l0, b0) is taken once, and each cell is then ONE v_max3_f32 (five instead of six
+// maxima per group, 20 instead of 24 per frame of sixteen cells; max is exact, so the association changes no bit).  With the
+// label-0 veto (ZL) the upper cell's l0 goes through a v_min first and nothing is shared.
+template <int M, bool ZL>
+__device__ __forceinline__ f32x2 label_pair_max(float l1, float b1, float l0, float b0, float p1, float p2, float veto1, float veto0)
+{
+    if constexpr (M == 4 && !ZL) {
+        const float m0 = __builtin_fmaxf(l0, b0);
+        return f32x2{__builtin_fmaxf(__builtin_fmaxf(m0, p1), p2), __builtin_fmaxf(__builtin_fmaxf(l1, b1), m0)};
+    } else {
+        return f32x2{cell_label_max<M, ZL>(l0, b0, p1, p2, veto0), cell_label_max<M, ZL>(l1, b1, l0, b0, veto1)};
+    }
+}
 // Score registers of the checkpointed kernel: cell k of a lane sits in P[2*(k>>2) + (k&1)][(k>>1)&1], i.e. the
 // two blank cells of a group of four share one 64-bit register pair and so do its two label cells - the emission
 // is then added to two cells per instruction (v_pk_add_f32: the vector ALU is what bounds this kernel).
@@ -421,9 +435,8 @@ __device__ __forceinline__ void frame_scores(f32x2 (&P)[8], float h1, float h2, 
     const float p2 = G > 0 ? P[2 * (G > 0 ? G - 1 : 0)][1] : h2;       // cell 4G-2 (blank)
     const float p3 = G > 0 ? P[2 * (G > 0 ? G - 1 : 0) + 1][0] : h3;   // cell 4G-3 (label)
     f32x2 ml, mb;
-    ml[1] = cell_label_max<M, ZL>(l1, b1, l0, b0, vz[2 * G + 1]);
+    ml = label_pair_max<M, ZL>(l1, b1, l0, b0, p1, p2, vz[2 * G + 1], vz[2 * G]);   // {lower, upper}
     mb[1] = cell_blank_max<M>(b1, l0, p1);
-    ml[0] = cell_label_max<M, ZL>(l0, b0, p1, p2, vz[2 * G]);
     mb[0] = cell_blank_max<M>(b0, p1, p3);
     P[2 * G + 1] = ml + E[G];
     P[2 * G] = mb + e00;

@@ -225,9 +225,8 @@ __device__ __forceinline__ void tp_frame(TpTile<M, ZL> &c, uint32_t t, float (&H
     if (live) {
         const float b0 = c.S[0], b1 = c.S[1], l0 = c.S[2], l1 = c.S[3];
         f32x2 ml, mb;
-        ml[1] = cell_label_max<M, ZL>(l1, b1, l0, b0, c.vz1);
+        ml = label_pair_max<M, ZL>(l1, b1, l0, b0, H[0], H[1], c.vz1, c.vz0);   // {lower, upper}
         mb[1] = cell_blank_max<M>(b1, l0, H[0]);
-        ml[0] = cell_label_max<M, ZL>(l0, b0, H[0], H[1], c.vz0);
         mb[0] = cell_blank_max<M>(b0, H[0], H[2]);
         const f32x2 sl = ml + cur.E, sb = mb + f32x2{cur.e0, cur.e0};
         c.S = f32x4{sb[0], sb[1], sl[0], sl[1]};
