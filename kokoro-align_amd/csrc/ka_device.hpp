@@ -92,6 +92,23 @@ __device__ __forceinline__ void row_reload(float &r, uint32_t lane_byte_off, con
 {
     asm volatile("global_load_dword %0, %1, %2" : "+v"(r) : "v"(lane_byte_off), "s"(row_base) : "memory");
 }
+// The same reload through a buffer descriptor: the row's byte offset is ONE 32-bit scalar (`soffset`), which a frame advances
+// and clamps to the last row with two scalar instructions (s_add_u32, s_min_u32) where the 64-bit pointer of row_reload took
+// six (add, compare, two selects, add, add-with-carry) - and a scalar instruction costs this kernel nearly half a vector
+// one.  Needs 4 T ld < 2^32.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// raw buffer descriptor over `bytes` bytes at `base` (both wave-uniform; stride 0, 32-bit data format: word 3 = 0x00020000)
+__device__ __forceinline__ u32x4 lp_descriptor(const void *base, uint64_t bytes)
+{
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    const uint32_t n = bytes > 0xffffffffull ? 0xffffffffu : (uint32_t)bytes;
+    return u32x4{(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a), (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xffffu)),
+                 (uint32_t)__builtin_amdgcn_readfirstlane((int)n), 0x00020000u};
+}
+__device__ __forceinline__ void row_reload_buf(float &r, uint32_t lane_byte_off, u32x4 rsrc /* wave-uniform */, uint32_t row_byte_off /* wave-uniform */)
+{
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "+v"(r) : "v"(lane_byte_off), "s"(rsrc), "s"(row_byte_off) : "memory");
+}
 // wait until at most N younger vector-memory operations are outstanding, then release `r`
 template <int N>
 __device__ __forceinline__ void row_wait(float &r)

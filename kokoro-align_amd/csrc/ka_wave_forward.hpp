@@ -306,7 +306,11 @@ __device__ __forceinline__ void forward_ck(const Lattice &d, int32_t *meta)
     absum = __builtin_fabsf(rows[0]);
 
     const char *ckp = reinterpret_cast<const char *>(d.bp);
-    const char *row_ahead = lp + (size_t)(D < T ? D : T - 1) * ld;   // row min(t+D, T-1) of the current frame t
+    // row min(t+D, T-1) of the current frame t, as a byte offset into the lattice's log-probs (forward_ck_kernel has made sure
+    // that it fits 32 bits)
+    const uint32_t ld32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ld), last_row = (T - 1u) * ld32;
+    uint32_t row_ahead = (D < T ? (uint32_t)D : T - 1u) * ld32;
+    const u32x4 lp_rsrc = lp_descriptor(d.lp, (uint64_t)T * ld);
     const uint32_t thr_real = dq != 0 ? 0u : T;   // floor(L*t/T) moves in this frame <=> rem + dr >= thr_real
     // static mask: frame 8k+7 when the ring has at least 8*(M-1) dead slots (7 unmasked frames leak 7*(M-1) cells and
     // lo reads M-1 below itself), else frame 4k+3.  Checkpoints (frame 32k+31) are masked frames either way.
@@ -332,8 +336,8 @@ __device__ __forceinline__ void forward_ck(const Lattice &d, int32_t *meta)
                 const float e0t = e0[dd & 1];
                 frame_scores<M, ZL, 3>(P, h1, h2, h3, E, vz, f32x2{e0t, e0t}, la, lrow);
                 // prefetch the row of frame t+D (the last row again once there is none: never consumed)
-                row_reload(rows[dd], lane_off, row_ahead);
-                row_ahead += t + D + 1 < T ? ld : 0;
+                row_reload_buf(rows[dd], lane_off, lp_rsrc, row_ahead);
+                row_ahead = min(row_ahead + ld32, last_row);
                 if (dd == D - 1 && ((tb | mask_every4) & 4u) != 0) {
 #ifndef KA_FWD_FLOOR
                     mask_scores<15>(P, mk, NINF);
@@ -500,6 +504,11 @@ __global__ __launch_bounds__(64, KA_FWD_MIN_WAVES) void forward_ck_kernel(const 
     const Lattice &d = lats[blockIdx.x];
     const int flags = __builtin_amdgcn_readfirstlane(meta_of(meta, d.idx)[2]);
     if (((flags & kFlagZeroLabel) != 0) != ZL) return;
+    // the row pipeline addresses the log-probs with 32-bit byte offsets: a lattice of 4 GB or more goes to the exact kernels
+    if ((uint64_t)(uint32_t)d.T * (uint64_t)d.ld * 4ull > 0xffffffffull) {
+        if (threadIdx.x == 0) atomicOr(&meta_of(meta, d.idx)[2], kFlagExact);
+        return;
+    }
     forward_ck<M, ZL>(d, meta);
 }
 

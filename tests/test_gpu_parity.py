@@ -234,6 +234,24 @@ def test_strided_device_input(ka):
     assert _same((p.cpu().numpy(), l.cpu().numpy(), s.cpu().numpy()), want)
 
 
+def test_rows_that_span_more_than_4_gb_go_to_the_exact_kernels(ka):
+    """forward_ck addresses the log-probs with 32-bit byte offsets (a buffer descriptor); a lattice whose rows span 4 GB or more
+    is declined there and done by the exact kernels, whose addresses are 64-bit: same result, status ok."""
+    import torch
+    rng = np.random.default_rng(12)
+    T, V, S = 130, 39, 40
+    lp, labels = _rand_case(rng, T, V, S)
+    want = O.ctc_best_path_c(lp, labels, 1000, 4)
+    ld = (1 << 23) + 64                        # floats between two rows: 130 rows x 32 MB = 4.36 GB
+    assert T * ld * 4 > (1 << 32)
+    wide = torch.zeros((T, ld), dtype=torch.float32, device="cuda")
+    wide[:, :V] = torch.from_numpy(lp).cuda()
+    (p, l, s), = ka.ctc_best_path_device([wide[:, :V]], [labels])
+    assert _same((p.cpu().numpy(), l.cpu().numpy(), s.cpu().numpy()), want)
+    del wide
+    torch.cuda.empty_cache()
+
+
 def test_log_softmax_kernel(ka):
     import torch
     rng = np.random.default_rng(11)
