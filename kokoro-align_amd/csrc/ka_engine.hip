@@ -314,7 +314,9 @@ int enqueue_tiles(ka_engine *e, const LaunchPlan &p, const BatchArgs &a, const D
         if (!tl.lds && p.alive_tiles <= 11 * n_cu / 4) tl.lds = 64 * 1024;
         ka::launch_forward_tiled128(tl, stream);
     } else {
-        tl.lds = lds;
+        // ... and when the tiles alive at once outnumber four per CU, no more than the kernel uses: with V = 39 and contiguous rows
+        // that is 26 KB, FIVE workgroups per CU - a slot-bound launch (the corpus) wants slots more than it wants fast tiles
+        tl.lds = (!e->tile_lds && p.alive_tiles > (int64_t)e->n_simd) ? 0u : lds;
         ka::launch_forward_tiled256(tl, stream);
     }
     return KA_OK;
@@ -704,7 +706,7 @@ int ka_debug_set_rc_gather(ka_engine *e, int32_t how)
 int ka_debug_set_tile_lds(ka_engine *e, int32_t bytes)
 {
     if (!e) return fail(KA_ERR_BAD_ARGS, "engine is NULL");
-    if (bytes != 0 && (bytes < (int32_t)ka::kTpLdsRequest || bytes > 160 * 1024)) return fail(KA_ERR_BAD_ARGS, "ka_debug_set_tile_lds: 0 or 40 KB .. 160 KB");
+    if (bytes < 0 || bytes > 160 * 1024) return fail(KA_ERR_BAD_ARGS, "ka_debug_set_tile_lds: 0 .. 160 KB");
     e->tile_lds = bytes;
     return KA_OK;
 }

@@ -24,6 +24,21 @@
 namespace ka {
 
 
+// LDS map of a workgroup: kTpRing blocks of rows - as they lie in memory when the rows are contiguous (32 x PITCH bytes, rounded up
+// to whole 1-KB LDS-DMA instructions: 5 KB for V = 39), else 32 rows of 256 bytes -, the ring's packets, the poll words, two
+// publish staging buffers, the diagnostic words (ticket at +48), two buffers of band words.  26.1 KB for V = 39 with contiguous
+// rows: FIVE workgroups per CU when the engine asks for no more (launches whose tiles outnumber the slots), 38.1 KB otherwise.
+template <int PITCH, bool CONTIG>
+struct Tp2Lds {
+    static constexpr int kRowDmas = !CONTIG ? kTpBlock : (kTpBlock * PITCH + 1023) / 1024;
+    static constexpr int kSlot = CONTIG ? kRowDmas * 1024 : kTpSlotBytes;
+    static constexpr int kHalo = kTpRing * kSlot;
+    static constexpr int kTicket = kHalo + kTpRing * kTpBlock * 16 + 16 + kTp2StageBytes + 48;
+    static constexpr int kTotal = kHalo + kTpRing * kTpBlock * 16 + 16 + kTp2StageBytes + 64 + 2 * kTp2BandBytes;
+};
+static_assert(Tp2Lds<256, false>::kTotal <= (int)kTpLdsRequest && Tp2Lds<256, true>::kTotal <= (int)kTpLdsRequest, "four workgroups per CU");
+static_assert(5 * ((Tp2Lds<156, true>::kTotal + 511) / 512 * 512) <= 160 * 1024, "five workgroups per CU with V = 39");
+
 // the barrier of an iteration: each side first finishes what the other is going to look at (the compute wavefront its LDS
 // writes; the feeder has already waited for its LDS-DMA with a counted vmcnt) - NOT the vmcnt(0) of __syncthreads, which
 // would drain the feeder's requests
@@ -118,11 +133,12 @@ __device__ __forceinline__ void tp2_run_tile(const Lattice &d, const TileTask &t
     const uint32_t last_row = c.T - 1;
     const uint32_t last_slot = (uint32_t)c.t_end - 1;     // this tile reads slots t_in .. t_end - 1
     auto ring = [](int32_t k) { return (uint32_t)((k % kTpRing + kTpRing) % kTpRing); };
-    constexpr int kRowDmas = !CONTIG ? kTpBlock : (kTpBlock * PITCH + 1023) / 1024;   // LDS-DMA instructions per block of rows
+    constexpr int kRowDmas = Tp2Lds<PITCH, CONTIG>::kRowDmas;   // LDS-DMA instructions per block of rows
+    constexpr uint32_t kSlot = Tp2Lds<PITCH, CONTIG>::kSlot;     // LDS bytes of a block of rows
     static_assert(CONTIG || PITCH == kTpRowBytes, "row-by-row staging uses 256-byte rows");
     auto issue_block = [&](int32_t k) {    // k >= 0
         const uint32_t tb = (uint32_t)k * kTpBlock, slot = ring(k);
-        lchar_t dst = (lchar_t)(uintptr_t)(c.lds_rows + slot * kTpSlotBytes);
+        lchar_t dst = (lchar_t)(uintptr_t)(c.lds_rows + slot * kSlot);
         if constexpr (!CONTIG) {
             const char *rp = c.lp + (size_t)(tb < last_row ? tb : last_row) * c.ld;
             if (tb + kTpBlock <= c.T) {
@@ -160,8 +176,8 @@ __device__ __forceinline__ void tp2_run_tile(const Lattice &d, const TileTask &t
     bool stale = false;
     auto landed_block = [&](int32_t k) {
         const uint32_t slot = ring(k);
-        const uint32_t r = c.lds_rows + slot * kTpSlotBytes + (uint32_t)lane * 16u;
-        constexpr int kReads = !CONTIG ? kTpSlotBytes / 1024 : kRowDmas;
+        const uint32_t r = c.lds_rows + slot * kSlot + (uint32_t)lane * 16u;
+        constexpr int kReads = kSlot / 1024;
         f32x4 v[kReads];
 #pragma unroll
         for (int j = 0; j < kReads; ++j) v[j] = lds_f32x4(r + j * 1024);
@@ -189,6 +205,11 @@ __device__ __forceinline__ void tp2_run_tile(const Lattice &d, const TileTask &t
     // Iterations kb0-2, kb0-1 prime the feeder's pipeline; iteration kb1+1 publishes the last block.
     for (int32_t it = kb0 - 2; it <= kb1 + 1; ++it) {
         const uint32_t tb = (uint32_t)(it * kTpBlock);              // (wraps in the priming iterations of block 0: not used there)
+        if ((verify & 4) && !feeder) {      // the compute wavefront's cycles at the barrier (words 8, 9: as the 128-position tile's)
+            const unsigned long long b0 = __builtin_amdgcn_s_memtime();
+            tp2_barrier();
+            if (it >= kb0 && it <= kb1 + 1) ((lu32_t)(uintptr_t)stat_lds)[8] += (uint32_t)(__builtin_amdgcn_s_memtime() - b0);
+        } else
         tp2_barrier();
         if (feeder) {
             phase(-1);
@@ -235,8 +256,9 @@ __device__ __forceinline__ void tp2_run_tile(const Lattice &d, const TileTask &t
             // t_end are filled (with -inf) after the loop, and the final progress word covers those
             if (published) tp_prog_store(c.prog_out, (tb < (uint32_t)c.t_end ? tb : (uint32_t)c.t_end) + 1);
         } else if (it >= kb0 && it <= kb1) {
+            const unsigned long long g0 = (verify & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
             const uint32_t slot = ring(it), nslot = ring(it + 1);
-            uint32_t rc = c.lds_rows + slot * kTpSlotBytes, rn = c.lds_rows + nslot * kTpSlotBytes;
+            uint32_t rc = c.lds_rows + slot * kSlot, rn = c.lds_rows + nslot * kSlot;
             uint32_t hc = c.lds_halo + slot * (kTpBlock * 16), hn = c.lds_halo + nslot * (kTpBlock * 16);
             asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
                          : "=&v"(rc), "=&v"(rn), "=&v"(hc), "=&v"(hn) : "s"(rc), "s"(rn), "s"(hc), "s"(hn));
@@ -275,7 +297,12 @@ __device__ __forceinline__ void tp2_run_tile(const Lattice &d, const TileTask &t
                 tp_block_frames<M, ZL, PITCH, true, 0>(c, tb, H, cur, nxt, A, NINF);
                 if ((tb + kTpBlock) % kCkFrames == 0 && (int32_t)(tb + kTpBlock) <= c.t_end && tb + kTpBlock < c.T) tp_checkpoint(c, tb + kTpBlock);
             }
-            if (verify & 4) ((lu32_t)(uintptr_t)stat_lds)[2] += (uint32_t)(__builtin_amdgcn_s_memtime() - fr0);
+            if (verify & 4) {
+                const unsigned long long now = __builtin_amdgcn_s_memtime();
+                // frames + checkpoint of the block | everything of the iteration that is not frames (set-up, checkpoint)
+                ((lu32_t)(uintptr_t)stat_lds)[2] += (uint32_t)(now - fr0);
+                ((lu32_t)(uintptr_t)stat_lds)[9] += (uint32_t)(fr0 - g0);
+            }
         }
     }
     // nothing of this workgroup may still be landing in LDS or in a register when it ends
@@ -313,6 +340,8 @@ __device__ __forceinline__ void tp2_run_tile(const Lattice &d, const TileTask &t
             st.phase[1] = sw[5] | ((unsigned long long)sw[6] << 32);
             st.phase[2] = sw[7] | ((unsigned long long)sw[10] << 32);   // (high half: HW_ID of the compute wavefront)
             st.wait_ticks = sw[1] | ((unsigned long long)sw[2] << 32);
+            st.extra[0] = sw[8] | ((unsigned long long)sw[2] << 32);    // compute wavefront: cycles at the barrier | cycles inside the frame blocks (+ checkpoint stores)
+            st.extra[1] = sw[9];                                         // ... and between a barrier and the block's first frame
             st.start_tick = __builtin_amdgcn_s_memtime() - stats_out->total_ticks;
             st.total_ticks = wall_clock64() - stats_out->start_tick;
             *stats_out = st;
@@ -361,17 +390,17 @@ __device__ __forceinline__ void tp2_run_tile(const Lattice &d, const TileTask &t
 
 // One workgroup of TWO wavefronts per tile (40 KB of LDS requested: four workgroups per CU).  Tickets as in
 // forward_tp_kernel: the tile a workgroup runs is drawn from a counter, tasks are sorted by first frame.
-static_assert(kTpRing * kTpSlotBytes + kTpRing * kTpBlock * 16 + 16 + kTp2StageBytes + 64 + 2 * kTp2BandBytes <= kTpLdsRequest, "LDS budget of the two-wavefront tile");
 template <int M, int PITCH, bool CONTIG>
 __global__ __launch_bounds__(128) void forward_tp2_kernel(const Lattice *__restrict__ lats, const TileTask *__restrict__ tasks, int n_tasks,
                                                           int32_t *meta, char *halo, uint32_t *prog, TileAux *aux, uint32_t *ticket, int verify, TpStats *stats)
 {
+    typedef Tp2Lds<PITCH, CONTIG> Lds;
     extern __shared__ __attribute__((aligned(16))) char tp_lds[];
     const uint32_t lds_rows = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&tp_lds[0];
-    const uint32_t lds_halo = lds_rows + kTpRing * kTpSlotBytes;
-    // (the ticket goes through a word of the dynamic LDS block: a static __shared__ variable on top of the 40 KB request would
-    //  leave room for three workgroups per CU instead of four)
-    volatile uint32_t *s_ticket = reinterpret_cast<volatile uint32_t *>(&tp_lds[kTpRing * kTpSlotBytes + kTpRing * kTpBlock * 16 + 16 + kTp2StageBytes + 48]);
+    const uint32_t lds_halo = lds_rows + Lds::kHalo;
+    // (the ticket goes through a word of the dynamic LDS block: a static __shared__ variable on top of the request would cost a
+    //  workgroup per CU)
+    volatile uint32_t *s_ticket = reinterpret_cast<volatile uint32_t *>(&tp_lds[Lds::kTicket]);
     if (threadIdx.x == 0) *s_ticket = atomicAdd(ticket, 1u);
     __syncthreads();
     const uint32_t tix = (uint32_t)__builtin_amdgcn_readfirstlane((int)*s_ticket);

@@ -7,7 +7,9 @@ namespace ka {
 template <int M, int PITCH, bool CONTIG>
 static void tiled256(const TileLaunch &a, hipStream_t s)
 {
-    hipLaunchKernelGGL((forward_tp2_kernel<M, PITCH, CONTIG>), dim3((unsigned)a.n_tasks), dim3(128), a.lds, s, a.lats, a.tasks, a.n_tasks, a.meta, a.halo, a.prog,
+    // (a.lds: what the engine wants a workgroup to hold - 0 = no more than the kernel uses)
+    const unsigned lds = a.lds > (unsigned)Tp2Lds<PITCH, CONTIG>::kTotal ? a.lds : (unsigned)Tp2Lds<PITCH, CONTIG>::kTotal;
+    hipLaunchKernelGGL((forward_tp2_kernel<M, PITCH, CONTIG>), dim3((unsigned)a.n_tasks), dim3(128), lds, s, a.lats, a.tasks, a.n_tasks, a.meta, a.halo, a.prog,
                        a.aux, a.ticket, a.verify, a.stats);
 }
 

@@ -15,6 +15,7 @@ b = DeviceBatch(lps, labs)
 e = b.engine
 e.set_mode(sys.argv[1] if len(sys.argv) > 1 else "auto")
 e.set_tile_width(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+e.set_tile_lds(int(sys.argv[3]) if len(sys.argv) > 3 else 0)      # bytes of LDS a tile workgroup asks for (0: the library's rule)
 e.set_profiling(True)
 e.set_verify(4)
 b.run(); b.run()
@@ -31,4 +32,4 @@ print(f"tiles {n}, frames per tile mean {frames.mean():.0f}; shader clock GHz me
 print(f"alive ns per frame: mean {np.mean(alive_ns / frames):.1f}, weighted {alive_ns.sum() / frames.sum():.1f}")
 print(f"cycles per frame inside the frame blocks: weighted {cyc_frames.sum() / frames.sum():.1f} = {cyc_frames.sum() / frames.sum() / clock.mean():.1f} ns")
 print(f"tile-frames {frames.sum() / 1e6:.1f} M; sum of alive time {alive_ns.sum() / 1e6:.1f} ms of slot time")
-e.set_verify(0); e.set_mode("auto"); e.set_tile_width(0)
+e.set_verify(0); e.set_mode("auto"); e.set_tile_width(0); e.set_tile_lds(0)
