@@ -312,7 +312,10 @@ __device__ __forceinline__ void chunk_map_task(const Lattice &d, uint32_t c, uin
 }
 
 // grid: x = chunk (numbered over all chunk-parallel lattices of the launch), y = segment of the band
-template <int M, bool ZL, int C>
+// (ONE kernel for transcripts with and without label 0, the two instances of the task behind a wave-uniform branch: as two
+//  kernels that each skip the other's lattices, the one with nothing to do still cost 0.13 ms on the corpus launch - 430 000
+//  workgroups that look their lattice up and leave - and both instances use the same 104 / 49 registers)
+template <int M, int C>
 __global__ __launch_bounds__(64) void chunk_map_kernel(const Lattice *__restrict__ lats, const int32_t *meta, int n_lats)
 {
     const Lattice &d = lats[__builtin_amdgcn_readfirstlane(lattice_of_chunk(lats, n_lats, (int64_t)blockIdx.x))];
@@ -320,12 +323,14 @@ __global__ __launch_bounds__(64) void chunk_map_kernel(const Lattice *__restrict
     const int32_t *mt = meta + 4 * (size_t)__builtin_amdgcn_readfirstlane(d.idx);
     const int flags = __builtin_amdgcn_readfirstlane(mt[2]);
     if (flags & (kFlagExact | kFlagDeclined)) return;
-    if (((flags & kFlagZeroLabel) != 0) != ZL) return;
     if (__builtin_amdgcn_readfirstlane(mt[0]) != kStatusOk || __builtin_amdgcn_readfirstlane(mt[1]) < 0) return;
     const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((int64_t)blockIdx.x - d.chunk0));
     if (c == 0) return;                                   // nothing lies before chunk 0
     __shared__ float s_rows[kCkFrames][64];
-    chunk_map_task<M, ZL, C>(d, c, (uint32_t)blockIdx.y, lane, s_rows);
+    if (flags & kFlagZeroLabel)
+        chunk_map_task<M, true, C>(d, c, (uint32_t)blockIdx.y, lane, s_rows);
+    else
+        chunk_map_task<M, false, C>(d, c, (uint32_t)blockIdx.y, lane, s_rows);
 }
 
 // 32 chunk maps -> one super-chunk map.  grid: x = blocks of 256 band positions, y = super-chunk, z = lattice

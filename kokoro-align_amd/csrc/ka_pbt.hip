@@ -10,13 +10,10 @@ template <int M>
 static void chunk_entries(const Lattice *lats, int n, int32_t *meta, hipStream_t s, unsigned total_chunks, unsigned max_seg, unsigned max_sup, unsigned max_w)
 {
     // (max_seg was counted by the host with the same rule: cm_out_for(max_w))
-    if (cm_out_for(max_w) == kCmOut) {
-        hipLaunchKernelGGL((chunk_map_kernel<M, false, kCmCells>), dim3(total_chunks, max_seg), dim3(64), 0, s, lats, meta, n);
-        hipLaunchKernelGGL((chunk_map_kernel<M, true, kCmCells>), dim3(total_chunks, max_seg), dim3(64), 0, s, lats, meta, n);
-    } else {
-        hipLaunchKernelGGL((chunk_map_kernel<M, false, kCmCellsWide>), dim3(total_chunks, max_seg), dim3(64), 0, s, lats, meta, n);
-        hipLaunchKernelGGL((chunk_map_kernel<M, true, kCmCellsWide>), dim3(total_chunks, max_seg), dim3(64), 0, s, lats, meta, n);
-    }
+    if (cm_out_for(max_w) == kCmOut)
+        hipLaunchKernelGGL((chunk_map_kernel<M, kCmCells>), dim3(total_chunks, max_seg), dim3(64), 0, s, lats, meta, n);
+    else
+        hipLaunchKernelGGL((chunk_map_kernel<M, kCmCellsWide>), dim3(total_chunks, max_seg), dim3(64), 0, s, lats, meta, n);
     hipLaunchKernelGGL(compose_maps_kernel, dim3(std::min(64u, (max_w + 255u) / 256u), max_sup, (unsigned)n), dim3(256), 0, s, lats, meta);
     hipLaunchKernelGGL(chain_entries_kernel, dim3((unsigned)n), dim3(256), 0, s, lats, meta);
 }

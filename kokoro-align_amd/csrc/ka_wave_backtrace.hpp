@@ -324,7 +324,7 @@ __device__ __forceinline__ void rc_walk_out(const uint32_t (&codes)[kCkFrames / 
 // (ka_debug_set_rc_gather): 27.2 -> 26.1 ms for 8192 lattices alone on the GPU, nothing with several launches in flight, and
 // the gathers read 47 GB more per step by the counters.  GO = false, the default, keeps everything in registers.
 template <int M, bool ZL, bool PAR, bool GO = false>
-__global__ __launch_bounds__(64, KA_RC_MIN_WAVES) void backtrace_rc_kernel(const Lattice *__restrict__ lats, const int32_t *meta, int n_lats)
+__device__ __forceinline__ void backtrace_rc_body(const Lattice *__restrict__ lats, const int32_t *meta, int n_lats)
 {
     const int which = PAR ? __builtin_amdgcn_readfirstlane(lattice_of_chunk(lats, n_lats, (int64_t)blockIdx.x)) : (int)blockIdx.x;
     const Lattice &d = lats[which];
@@ -557,6 +557,25 @@ __global__ __launch_bounds__(64, KA_RC_MIN_WAVES) void backtrace_rc_kernel(const
         if (r0 < R32) { r0 += T; q0 -= 1; }
         r0 -= R32;
     }
+}
+
+// PAR = false: two kernels per launch (ZL: the transcript contains label 0), each skips the other's lattices - as in the forward kernels
+template <int M, bool ZL, bool PAR, bool GO = false>
+__global__ __launch_bounds__(64, KA_RC_MIN_WAVES) void backtrace_rc_kernel(const Lattice *__restrict__ lats, const int32_t *meta, int n_lats)
+{
+    backtrace_rc_body<M, ZL, PAR, GO>(lats, meta, n_lats);
+}
+// PAR = true (one wavefront per chunk of every chunk-parallel lattice): ONE kernel, the two instances behind a wave-uniform branch -
+// a grid of 430 000 workgroups that only look their lattice up and leave cost the corpus launch 0.1 ms; 53 / 54 registers
+template <int M>
+__global__ __launch_bounds__(64, KA_RC_MIN_WAVES) void backtrace_rc_chunks_kernel(const Lattice *__restrict__ lats, const int32_t *meta, int n_lats)
+{
+    const Lattice &d = lats[__builtin_amdgcn_readfirstlane(lattice_of_chunk(lats, n_lats, (int64_t)blockIdx.x))];
+    const int flags = __builtin_amdgcn_readfirstlane(meta[4 * (size_t)d.idx + 2]);
+    if (flags & kFlagZeroLabel)
+        backtrace_rc_body<M, true, true>(lats, meta, n_lats);
+    else
+        backtrace_rc_body<M, false, true>(lats, meta, n_lats);
 }
 
 // best_labels = lab'[best_path], best_scores[t] = lp[t, best_labels[t]]  (align.py:105-107)

@@ -29,8 +29,7 @@ void launch_backtrace_rc_serial(int max_move, const Lattice *lats, int n, int32_
 template <int M>
 static void rc_chunks(const Lattice *lats, int n, int32_t *meta, hipStream_t s, unsigned total_chunks)
 {
-    hipLaunchKernelGGL((backtrace_rc_kernel<M, false, true>), dim3(total_chunks), dim3(64), 0, s, lats, meta, n);
-    hipLaunchKernelGGL((backtrace_rc_kernel<M, true, true>), dim3(total_chunks), dim3(64), 0, s, lats, meta, n);
+    hipLaunchKernelGGL((backtrace_rc_chunks_kernel<M>), dim3(total_chunks), dim3(64), 0, s, lats, meta, n);
 }
 
 void launch_backtrace_rc_chunks(int max_move, const Lattice *lats, int n, int32_t *meta, hipStream_t s, unsigned total_chunks)
