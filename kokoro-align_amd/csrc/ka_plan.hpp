@@ -230,7 +230,7 @@ struct AutoCosts {
     double wave_chain = 0.224, wave_alu = 0.097;
     double tile_chain = 0.095, tile_slot = 0.12, tile_alu = 0.023;
     double tile_stretch = 0.55, wave_stretch = 0.40;
-    double serial_chain = 0.173, serial_thr = 0.0675;
+    double serial_chain = 0.19, serial_thr = 0.0675;      // (0.173 - a lone walk - until round 4: beside the chunk maps of the same launch a walk takes 6.1 us per chunk, not 5.5)
     double par_frame = 0.00055, par_fixed = 120.0;      // (0.00066 until round 4's 18-cell map wavefronts: three map wavefronts per chunk became one)
     double fork = 15.0;      // a second stream and its two event waits
 };
