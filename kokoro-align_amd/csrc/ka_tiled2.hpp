@@ -76,6 +76,8 @@ __device__ __forceinline__ void tp2_run_tile(const Lattice &d, const TileTask &t
         stats_out->start_tick = (unsigned long long)wall_clock64();
         stats_out->total_ticks = __builtin_amdgcn_s_memtime();
     }
+    // the compute wavefront is the chain: where it shares a SIMD with feeders and with other kernels' wavefronts it issues first
+    if (!feeder) __builtin_amdgcn_s_setprio(3);
     const float NINF = ninf();
     TpTile<M, ZL> c;
     c.T = (uint32_t)__builtin_amdgcn_readfirstlane(d.T);
