@@ -164,7 +164,7 @@ int ka_debug_set_split(ka_engine *e, int32_t n_tiled, int32_t n_parallel);
  * longest it runs tiled and how many it walks back chunk-parallel. */
 int ka_debug_auto_split(const int64_t *T, int32_t n, int32_t tiles_alive, int32_t n_simd, int32_t *n_tiled, int32_t *n_parallel);
 /* LDS bytes a tile workgroup of the tiled form requests (0 = the library's choice; 40 KB lets four workgroups share a CU, 80 KB
- * two; a request below what the kernel uses - 26-52 KB by tile width, V and row layout - is raised to that): an occupancy
+ * two; a request below what the kernel uses - 27-52 KB by tile width, V and row layout - is raised to that): an occupancy
  * experiment knob, results are identical. */
 int ka_debug_set_tile_lds(ka_engine *e, int32_t bytes);
 /* Positions per tile of the tiled form: 256 (four cells per lane, two wavefronts per tile: ka_tiled2.hpp), 128 (two cells per lane,

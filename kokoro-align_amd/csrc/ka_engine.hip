@@ -315,7 +315,7 @@ int enqueue_tiles(ka_engine *e, const LaunchPlan &p, const BatchArgs &a, const D
         ka::launch_forward_tiled128(tl, stream);
     } else {
         // ... and when the tiles alive at once outnumber four per CU, no more than the kernel uses: with V = 39 and contiguous rows
-        // that is 26 KB, FIVE workgroups per CU - a slot-bound launch (the corpus) wants slots more than it wants fast tiles
+        // that is 27 KB, FIVE workgroups per CU - a slot-bound launch (the corpus) wants slots more than it wants fast tiles
         tl.lds = (!e->tile_lds && p.alive_tiles > (int64_t)e->n_simd) ? 0u : lds;
         ka::launch_forward_tiled256(tl, stream);
     }

@@ -381,7 +381,7 @@ def test_corpus_under_auto_sample_vs_oracle_and_properties_on_all():
 @pytest.mark.parametrize("width,lds", [(256, 1024), (256, 40 * 1024), (256, 80 * 1024), (128, 1024), (128, 64 * 1024)])
 def test_tile_workgroups_per_cu_do_not_change_results(books_on_device, width, lds):
     """ka_debug_set_tile_lds: how much LDS a tile workgroup asks for, i.e. how many share a CU - a request below what the kernel uses
-    (26-52 KB by tile width, V and row layout) is raised to that: five 256-position tiles per CU with V = 39, what the library
+    (27-52 KB by tile width, V and row layout) is raised to that: five 256-position tiles per CU with V = 39, what the library
     picks by itself when a launch's tiles outnumber four per CU; 80 KB keeps two per CU.  Same paths, same scores."""
     from kokoro_align_amd.align import DeviceBatch
     lps, labs = books_on_device("kokoro")
