@@ -27,7 +27,7 @@ namespace ka {
 // LDS map of a workgroup: kTpRing blocks of rows - as they lie in memory when the rows are contiguous (32 x PITCH bytes, rounded up
 // to whole 1-KB LDS-DMA instructions: 5 KB for V = 39), else 32 rows of 256 bytes -, the ring's packets, the poll words, two
 // publish staging buffers, the diagnostic words (ticket at +48), two buffers of band words.  27.1 KB for V = 39 with contiguous
-// rows: FIVE workgroups per CU when the engine asks for no more (launches whose tiles outnumber the slots), 38.1 KB otherwise.
+// rows: FIVE workgroups per CU when the engine asks for no more (launches whose tiles outnumber the slots), 39.1 KB otherwise.
 template <int PITCH, bool CONTIG>
 struct Tp2Lds {
     static constexpr int kRowDmas = !CONTIG ? kTpBlock : (kTpBlock * PITCH + 1023) / 1024;
